@@ -1,0 +1,397 @@
+// C ABI of include/rt_hip.h: context, world upload, render launches.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (raytracer_amd/csrc/Makefile).
+// -ffp-contract=off applies to the host code here too: the film constants below
+// are computed with the same once-rounded float operations as main.cpp:350-368.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_kernels.hpp"
+#include "rt_layout.hpp"
+
+struct rt_context {
+    int device = -1;
+    hipDeviceProp_t props{};
+    std::string error;
+
+    // world: one LDS image per intersection mode
+    bool has_world = false;
+    bool mixed = false;             // spheres and rectangles both present
+    rt_camera camera{};
+    uint32_t image_words[2] = {0, 0};
+    uint4* d_image[2] = {nullptr, nullptr};
+
+    // buffers behind rt_render (host outputs); grow-only
+    uint32_t* d_pixels = nullptr;
+    float* d_radiance = nullptr;
+    size_t pixel_capacity = 0;
+    unsigned long long* d_rays = nullptr;
+
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+rt_status fail(rt_context* ctx, rt_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    return st;
+}
+
+#define RT_HIP_CHECK(ctx, call)                                                                          \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s: %s", \
+                        #call, hipGetErrorString(e_));                                                   \
+    } while (0)
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+struct Launch {
+    rt::KernelParams kp;
+    uint32_t blocks;
+    int imode, rmode;
+};
+
+rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out) {
+    if (!p) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->struct_size != sizeof(rt_render_params))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_params.struct_size %u != %zu (ABI mismatch)", p->struct_size,
+                    sizeof(rt_render_params));
+    if (p->width == 0 || p->height == 0 || p->width > (1u << 16) || p->height > (1u << 16))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "image size %ux%u out of range (1..65536)", p->width, p->height);
+    if (p->samples_per_pixel == 0 || p->samples_per_pixel > (1u << 20))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "samples_per_pixel %u out of range (1..1048576)", p->samples_per_pixel);
+    if (p->max_bounces == 0 || p->max_bounces > 1024)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_bounces %u out of range (1..1024)", p->max_bounces);
+    if (p->row_begin >= p->row_end || p->row_end > p->height)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rows [%u,%u) not inside the image height %u", p->row_begin, p->row_end,
+                    p->height);
+    if (p->band_rows && (p->band_count == 0 || p->band_index >= p->band_count))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "band_index %u / band_count %u invalid", p->band_index, p->band_count);
+    if (p->rng_mode != RT_RNG_ROW_SERIAL && p->rng_mode != RT_RNG_PIXEL)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %u", p->rng_mode);
+    if (p->intersect_mode != RT_INTERSECT_WIDE8 && p->intersect_mode != RT_INTERSECT_SCALAR)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown intersect_mode %u", p->intersect_mode);
+    if (p->seed_constant == 0 && p->rng_mode == RT_RNG_ROW_SERIAL)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "seed_constant 0 gives the all-zero xorshift state");
+
+    rt::KernelParams& k = out->kp;
+    std::memset(&k, 0, sizeof k);
+    k.width = p->width; k.height = p->height; k.spp = p->samples_per_pixel;
+    k.local_rows = rt_local_row_count(p);
+    if (k.local_rows == 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "this band owns no rows");
+    k.row_begin = p->row_begin;
+    k.band_rows = p->band_rows; k.band_index = p->band_index; k.band_count = p->band_count ? p->band_count : 1;
+    k.max_bounces = p->max_bounces;
+    k.min_hit = p->min_hit_distance; k.plane_tol = p->plane_tolerance;
+    k.seed_constant = p->seed_constant;
+    k.output_sum = (p->flags & RT_FLAG_OUTPUT_SUM) ? 1u : 0u;
+    out->imode = (int)p->intersect_mode;
+    out->rmode = (int)p->rng_mode;
+    k.scene_words = ctx->image_words[out->imode];
+
+    uint64_t lanes;
+    if (p->rng_mode == RT_RNG_ROW_SERIAL) {
+        k.rows_per_order = p->rows_per_order ? p->rows_per_order : k.local_rows;
+        if (p->band_rows && k.band_count > 1 && (p->band_rows % k.rows_per_order))
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "band_rows %u must be a multiple of rows_per_order %u", p->band_rows,
+                        k.rows_per_order);
+        k.order_count = (k.local_rows + k.rows_per_order - 1) / k.rows_per_order;
+        k.lanes_per_pixel = 1; k.samples_per_lane = k.spp;
+        k.tile_w = k.tile_h = 1; k.tiles_x = k.tiles_y = 1;
+        lanes = k.order_count;
+    } else {
+        uint32_t B = p->lanes_per_pixel;
+        if (!is_pow2(B) || B > 64 || (p->samples_per_pixel % B))
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                        "lanes_per_pixel %u must be a power of two <= 64 dividing samples_per_pixel %u", B,
+                        p->samples_per_pixel);
+        k.lanes_per_pixel = B;
+        k.samples_per_lane = p->samples_per_pixel / B;
+        k.batch_offset = p->batch_offset;
+        // 64/B pixels per wave, as square a tile as the power of two allows.
+        uint32_t pixels_per_wave = 64 / B, tw = 1;
+        while (tw * tw < pixels_per_wave) tw <<= 1;
+        k.tile_w = tw; k.tile_h = pixels_per_wave / tw;
+        k.tiles_x = (k.width + k.tile_w - 1) / k.tile_w;
+        k.tiles_y = (k.local_rows + k.tile_h - 1) / k.tile_h;
+        k.rows_per_order = 1; k.order_count = 0;
+        lanes = (uint64_t)k.tiles_x * k.tiles_y * 64;
+    }
+    uint64_t blocks = (lanes + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
+    out->blocks = (uint32_t)blocks;
+
+    // Film constants (main.cpp:350-368), rounded operation by operation.
+    const rt_camera& c = ctx->camera;
+    float aspect = (float)(int32_t)p->width / (float)(int32_t)p->height;
+    float film_distance = 1.0f;
+    for (int i = 0; i < 3; ++i) {
+        k.cam_pos[i] = c.position[i];
+        k.cam_x[i] = c.x_axis[i];
+        k.cam_y[i] = c.y_axis[i];
+        k.film_center[i] = c.position[i] - c.z_axis[i] * film_distance;
+    }
+    float film_w = 1.0f * aspect, film_h = 1.0f;
+    k.half_w = film_w * 0.5f;
+    k.half_h = film_h * 0.5f;
+    k.pixel_w = 0.5f / (float)(int32_t)p->width;
+    k.pixel_h = 0.5f / (float)(int32_t)p->height;
+    return RT_OK;
+}
+
+template <int IMODE, int RMODE, bool MIXED>
+hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels, float* d_radiance,
+                          unsigned long long* d_rays, hipStream_t stream) {
+    auto kernel = rt::render_kernel<IMODE, RMODE, MIXED>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(L.blocks), dim3(rt::BLOCK_THREADS), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
+                       d_rays);
+    return hipGetLastError();
+}
+
+hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, float* d_radiance,
+                  unsigned long long* d_rays, hipStream_t stream) {
+    const uint4* image = ctx->d_image[L.imode];
+    size_t lds = (size_t)ctx->image_words[L.imode] * 4;
+    const bool wide = L.imode == RT_INTERSECT_WIDE8, rows = L.rmode == RT_RNG_ROW_SERIAL;
+    if (wide && rows) {
+        return ctx->mixed ? launch_variant<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true>(L, lds, image, d_pixels, d_radiance, d_rays, stream)
+                          : launch_variant<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
+    } else if (wide) {
+        return ctx->mixed ? launch_variant<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true>(L, lds, image, d_pixels, d_radiance, d_rays, stream)
+                          : launch_variant<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
+    } else if (rows) {
+        return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
+    }
+    return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_status_string(rt_status status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case RT_ERR_NO_DEVICE: return "no usable HIP device";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_NO_WORLD: return "no world uploaded";
+        case RT_ERR_TOO_LARGE: return "scene too large for LDS";
+        case RT_ERR_OUT_OF_MEMORY: return "out of device memory";
+    }
+    return "unknown status";
+}
+
+rt_status rt_create(int device_ordinal, rt_context** out_context) {
+    if (!out_context) return RT_ERR_INVALID_ARGUMENT;
+    *out_context = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= count) return RT_ERR_NO_DEVICE;
+    rt_context* ctx = new (std::nothrow) rt_context;
+    if (!ctx) return RT_ERR_OUT_OF_MEMORY;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&ctx->props, device_ordinal) != hipSuccess ||
+        hipMalloc(&ctx->d_rays, sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    *out_context = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
+    if (ctx->d_pixels) (void)hipFree(ctx->d_pixels);
+    if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
+    if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+}
+
+const char* rt_error_string(const rt_context* ctx) { return ctx ? ctx->error.c_str() : "context is NULL"; }
+
+rt_status rt_get_device_info(const rt_context* ctx, rt_device_info* info) {
+    if (!ctx || !info) return RT_ERR_INVALID_ARGUMENT;
+    std::memset(info, 0, sizeof *info);
+    std::snprintf(info->name, sizeof info->name, "%s", ctx->props.name);
+    std::snprintf(info->arch, sizeof info->arch, "%s", ctx->props.gcnArchName);
+    if (char* colon = std::strchr(info->arch, ':')) *colon = 0;
+    info->compute_units = (uint32_t)ctx->props.multiProcessorCount;
+    info->clock_khz = (uint32_t)ctx->props.clockRate;
+    info->lds_bytes_per_workgroup = (uint32_t)ctx->props.sharedMemPerBlockOptin;
+    if (info->lds_bytes_per_workgroup == 0) info->lds_bytes_per_workgroup = (uint32_t)ctx->props.sharedMemPerBlock;
+    info->global_memory_bytes = ctx->props.totalGlobalMem;
+    // 4 SIMDs x 32 lanes per CU, one FMA (2 flop) per lane per clock when packed-FP32 issue is sustained.
+    info->fp32_vector_peak_tflops = (double)info->compute_units * 128.0 * 2.0 * (double)info->clock_khz * 1.0e3 / 1.0e12;
+    return RT_OK;
+}
+
+void rt_default_params(rt_render_params* p, uint32_t width, uint32_t height, uint32_t spp) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->width = width; p->height = height; p->samples_per_pixel = spp;
+    p->row_begin = 0; p->row_end = height;
+    p->band_rows = 0; p->band_index = 0; p->band_count = 1;
+    p->max_bounces = 8;             // main.cpp:275
+    p->min_hit_distance = 0.001f;   // main.cpp:29
+    p->plane_tolerance = 0.001f;    // main.cpp:28
+    p->seed_constant = 262346u;     // main.cpp:370
+    p->rng_mode = RT_RNG_PIXEL;
+    p->rows_per_order = 1;          // main.cpp:433
+    p->lanes_per_pixel = 1;
+    p->batch_offset = 0;
+    p->intersect_mode = RT_INTERSECT_WIDE8;
+    p->flags = 0;
+}
+
+uint32_t rt_local_row_count(const rt_render_params* p) {
+    if (!p || p->row_end <= p->row_begin) return 0;
+    uint32_t total = p->row_end - p->row_begin;
+    if (p->band_rows == 0 || p->band_count <= 1) return total;
+    uint32_t bands = (total + p->band_rows - 1) / p->band_rows, n = 0;
+    for (uint32_t b = p->band_index; b < bands; b += p->band_count) {
+        uint32_t lo = b * p->band_rows, hi = lo + p->band_rows < total ? lo + p->band_rows : total;
+        n += hi - lo;
+    }
+    return n;
+}
+
+uint32_t rt_global_row(const rt_render_params* p, uint32_t local) {
+    if (p->band_rows == 0 || p->band_count <= 1) return p->row_begin + local;
+    uint32_t band = local / p->band_rows, within = local % p->band_rows;
+    return p->row_begin + (band * p->band_count + p->band_index) * p->band_rows + within;
+}
+
+rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!w || !w->camera || !w->materials || w->material_count == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "world needs a camera and at least the sky material");
+    if ((w->plane_count && !w->planes) || (w->sphere_count && !w->spheres) || (w->rectangle_count && !w->rectangles))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "non-zero primitive count with a NULL array");
+    if (w->material_count > rt::TAG_MATERIAL_MASK)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "too many materials");
+    for (uint32_t i = 0; i < w->plane_count; ++i)
+        if (w->planes[i].material_index >= w->material_count) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "plane %u: material index out of range", i);
+    for (uint32_t i = 0; i < w->sphere_count; ++i)
+        if (w->spheres[i].material_index >= w->material_count) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sphere %u: material index out of range", i);
+    for (uint32_t i = 0; i < w->rectangle_count; ++i)
+        if (w->rectangles[i].material_index >= w->material_count) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rectangle %u: material index out of range", i);
+
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
+    std::vector<uint32_t> images[2] = {rt::pack_scene_image(*w, true), rt::pack_scene_image(*w, false)};
+    for (int i = 0; i < 2; ++i)
+        if (images[i].size() * 4 > lds_limit)
+            return fail(ctx, RT_ERR_TOO_LARGE, "scene image is %zu bytes, the LDS of one workgroup holds %zu", images[i].size() * 4,
+                        lds_limit);
+    RT_HIP_CHECK(ctx, hipDeviceSynchronize());   // no render may still read the old images
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->d_image[i]) { RT_HIP_CHECK(ctx, hipFree(ctx->d_image[i])); ctx->d_image[i] = nullptr; }
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_image[i], images[i].size() * 4));
+        RT_HIP_CHECK(ctx, hipMemcpy(ctx->d_image[i], images[i].data(), images[i].size() * 4, hipMemcpyHostToDevice));
+        ctx->image_words[i] = (uint32_t)images[i].size();
+    }
+    ctx->camera = *w->camera;
+    ctx->mixed = w->sphere_count && w->rectangle_count;
+    ctx->has_world = true;
+    return RT_OK;
+}
+
+rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
+                           uint64_t* d_rays, void* hip_stream) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L);
+    if (st != RT_OK) return st;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
+    if (rays) RT_HIP_CHECK(ctx, hipMemsetAsync(rays, 0, sizeof(unsigned long long), stream));
+    const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
+    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, stream));
+    RT_HIP_CHECK(ctx, launch(ctx, L, d_pixels, d_radiance, rays, stream));
+    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));
+    ctx->timed = timed;
+    return RT_OK;
+}
+
+rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L);
+    if (st != RT_OK) return st;
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t count = (size_t)L.kp.local_rows * L.kp.width;
+    if (count > ctx->pixel_capacity) {
+        if (ctx->d_pixels) { RT_HIP_CHECK(ctx, hipFree(ctx->d_pixels)); ctx->d_pixels = nullptr; }
+        if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
+        ctx->pixel_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pixels, count * sizeof(uint32_t)));
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
+        ctx->pixel_capacity = count;
+    }
+    st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, radiance ? ctx->d_radiance : nullptr,
+                          reinterpret_cast<uint64_t*>(ctx->d_rays), nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(nullptr));
+    if (pixels) RT_HIP_CHECK(ctx, hipMemcpy(pixels, ctx->d_pixels, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (radiance) RT_HIP_CHECK(ctx, hipMemcpy(radiance, ctx->d_radiance, count * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (rays) {
+        unsigned long long r = 0;
+        RT_HIP_CHECK(ctx, hipMemcpy(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost));
+        *rays = r;
+    }
+    return RT_OK;
+}
+
+rt_status rt_resolve_device(rt_context* ctx, const float* d_sum, uint64_t pixel_count, uint32_t total_samples,
+                            uint32_t* d_pixels, float* d_mean, void* hip_stream) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!d_sum || pixel_count == 0 || total_samples == 0 || pixel_count > (1ull << 33))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve_device: bad sum pointer, pixel count or sample count");
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint32_t blocks = (uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS);
+    hipLaunchKernelGGL(rt::resolve_kernel, dim3(blocks), dim3(rt::BLOCK_THREADS), 0, static_cast<hipStream_t>(hip_stream), d_sum,
+                       pixel_count, (float)total_samples, d_pixels, d_mean);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+rt_status rt_last_kernel_ms(rt_context* ctx, float* out_ms) {
+    if (!ctx || !out_ms) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->timed) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "the last render was not launched with RT_FLAG_TIME_KERNEL");
+    RT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_stop));
+    RT_HIP_CHECK(ctx, hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+    return RT_OK;
+}
+
+}  // extern "C"

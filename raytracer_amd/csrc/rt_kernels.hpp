@@ -1,0 +1,485 @@
+// gfx950 device code of the path-tracing hot path.
+//
+// Execution shape: one lane carries one random stream and traces the samples
+// that stream owns, one path after another (RT_RNG_PIXEL: the samples of one
+// (pixel, batch); RT_RNG_ROW_SERIAL: every sample of a WorkOrder's rows, as the
+// reference's worker thread does, main.cpp:370-392).  The 64 lanes of a wave
+// step through ONE loop whose body is "start a path if idle; intersect; shade";
+// a lane whose path ended picks up its next sample in the next iteration, so
+// lanes at different bounce depths and different samples still execute the
+// intersection - the only expensive part - together.  The wave leaves the loop
+// when a ballot shows no lane has work.  The scene image is staged once per
+// workgroup into LDS and every primitive record is read with a wave-uniform
+// (broadcast) address: lanes are rays, the loop runs over primitives, where the
+// reference puts primitives in SIMD lanes and loops over rays.
+//
+// Arithmetic: this file must be compiled with -ffp-contract=off.  Every scalar
+// operation then rounds once, in the reference's source order, and the only
+// fused multiply-adds are the __builtin_fmaf calls that stand where the reference
+// calls FMulAdd/FMulSub (simd.h:91-93,200-202; main.cpp:67,86).  Division and
+// square root are the correctly rounded forms.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "rt_layout.hpp"
+
+namespace rt {
+
+struct KernelParams {
+    uint32_t width, height, spp;
+    uint32_t local_rows, row_begin, band_rows, band_index, band_count;
+    uint32_t max_bounces;
+    float min_hit, plane_tol;
+    uint32_t seed_constant;
+    uint32_t rows_per_order, order_count;               // ROW_SERIAL
+    uint32_t lanes_per_pixel, samples_per_lane, batch_offset;  // PIXEL
+    uint32_t tile_w, tile_h, tiles_x, tiles_y;          // PIXEL: pixels of one wave
+    uint32_t output_sum;
+    uint32_t scene_words;
+    float cam_pos[3], cam_x[3], cam_y[3], film_center[3];
+    float half_w, half_h, pixel_w, pixel_h;
+};
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float f) { return mk(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// math_vector.h:153-155: products and sums rounded one by one, left to right.
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// simd.h:91-93: fma(x,x', fma(y,y', z*z')).
+__device__ __forceinline__ float dot_fma(V3 a, V3 b) {
+    return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z));
+}
+// math_vector.h:167-171: v * (1 / sqrtf(v.v)).
+__device__ __forceinline__ V3 normalize(V3 v) {
+    const float f = 1.0f / __builtin_sqrtf(dot(v, v));
+    return mk(v.x * f, v.y * f, v.z * f);
+}
+__device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// math_util.h:32-50.  (float)U32Max is 2^32, so the division is an exact scaling.
+__device__ __forceinline__ uint32_t xorshift32(uint32_t& s) {
+    uint32_t x = s;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    s = x;
+    return x;
+}
+__device__ __forceinline__ float random_unilateral(uint32_t& s) { return (float)xorshift32(s) * 0x1.0p-32f; }
+__device__ __forceinline__ float random_bilateral(uint32_t& s) { return 2.0f * random_unilateral(s) - 1.0f; }
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+// Stream of (pixel, batch): rooted in the reference's seed for the one-row
+// WorkOrder [y, y+1) (main.cpp:370); never zero (math_util.h:32).
+__device__ __forceinline__ uint32_t pixel_stream_seed(uint32_t seed_constant, uint32_t x, uint32_t y, uint32_t batch) {
+    uint32_t root = seed_constant * (y + (y + 1u) * 36u);
+    uint32_t h = fmix32(root + 0x9E3779B9u * (x + 1u));
+    h = fmix32(h ^ (0x85EBCA6Bu * (batch + 1u)));
+    return h ? h : 0x9E3779B9u;
+}
+
+__device__ __forceinline__ float clampf(float lo, float v, float hi) {  // math_util.h:14-22
+    if (v < lo) return lo;
+    else if (v > hi) return hi;
+    else return v;
+}
+
+// math_util.h:102-125.  powf is evaluated in double and rounded once.
+__device__ __forceinline__ float linear_to_srgb(float value) {
+    value = clampf(0.0f, value, 1.0f);
+    float result = value * 12.92f;
+    if (value >= 0.0031308f) {
+        float p = (float)pow((double)value, (double)(1.0f / 2.4f));
+        result = (1.055f * p) - 0.055f;
+    }
+    return result;
+}
+__device__ __forceinline__ uint32_t pack_srgb(V3 c) {
+    return (255u << 24) | ((uint32_t)(int32_t)(255 * linear_to_srgb(c.x)) << 16) |
+           ((uint32_t)(int32_t)(255 * linear_to_srgb(c.y)) << 8) | ((uint32_t)(int32_t)(255 * linear_to_srgb(c.z)) << 0);
+}
+
+__device__ __forceinline__ uint32_t global_row(const KernelParams& p, uint32_t local) {
+    if (p.band_rows == 0 || p.band_count <= 1) return p.row_begin + local;
+    uint32_t band = local / p.band_rows, within = local % p.band_rows;
+    return p.row_begin + (band * p.band_count + p.band_index) * p.band_rows + within;
+}
+
+struct SceneView {
+    const float* f;       // LDS image as floats
+    const uint32_t* u;    // ... and as words
+    uint32_t n_planes, n_spheres, n_rects;
+    uint32_t off_planes, off_spheres, off_tags, off_rects, off_mats;
+};
+
+// World intersection.  best_id: 0 = miss, 1+i plane i, 1+np+k sphere slot k,
+// 1+np+ns+k rectangle slot k (slots in the image's order).
+template <int IMODE, bool MIXED>
+__device__ __forceinline__ void intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
+                                                float& best_t, uint32_t& best_id) {
+    best_t = 3.402823466e+38f;  // F32Max
+    best_id = 0;
+    uint32_t best_lane = 0;     // WIDE8 + MIXED: AVX lane of the best hit when it is a sphere
+
+    // Planes: scalar code in both reference routines (main.cpp:37-50, 168-180).
+    for (uint32_t i = 0; i < sv.n_planes; ++i) {
+        const float4 pl = *reinterpret_cast<const float4*>(sv.f + sv.off_planes + PLANE_WORDS * i);
+        V3 n = mk(pl.x, pl.y, pl.z);
+        float denom = dot(n, d);
+        if ((denom < -plane_tol) || (denom > plane_tol)) {
+            float t = (-pl.w - dot(n, o)) / denom;
+            if (t > min_hit && t < best_t) { best_t = t; best_id = 1 + i; }
+        }
+    }
+
+    // Spheres (main.cpp:60-91 / 182-207).
+    if (sv.n_spheres) {
+        const float a = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(d, d) : dot(d, d);
+        const float denom = 2.0f * a;
+        for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+            const float4 sp = *reinterpret_cast<const float4*>(sv.f + sv.off_spheres + SPHERE_WORDS * k);
+            V3 cto = o - mk(sp.x, sp.y, sp.z);
+            float disc, b;
+            if (IMODE == RT_INTERSECT_WIDE8) {
+                b = 2.0f * dot_fma(d, cto);
+                float c = dot_fma(cto, cto) - sp.w;
+                disc = __builtin_fmaf(b, b, -(4.0f * a * c));      // FMulSub(b, b, 4ac)
+            } else {
+                b = 2 * dot(d, cto);
+                float c = dot(cto, cto) - sp.w;
+                disc = b * b - 4 * a * c;
+            }
+            if (disc > 0.0f) {
+                float root = __builtin_sqrtf(disc);
+                float tp = (-b + root) / denom;
+                float tn = (-b - root) / denom;
+                float t = tp;
+                if (tn > min_hit && tn < tp) t = tn;
+                if (t > min_hit && t < best_t) {
+                    best_t = t;
+                    best_id = 1 + sv.n_planes + k;
+                    if (MIXED) best_lane = sv.u[sv.off_tags + k] >> TAG_LANE_SHIFT;
+                }
+            }
+        }
+    }
+
+    // Rectangles (main.cpp:96-129 / 212-239): ray into the rectangle's frame, hit the
+    // z = 0 plane, test against the unit square.
+    for (uint32_t k = 0; k < sv.n_rects; ++k) {
+        const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_WORDS * k);
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        float lox, loy, loz, ldx, ldy, ldz;
+        if (IMODE == RT_INTERSECT_WIDE8) {
+            // DotProduct(LaneVector4): fma(x,x', fma(y,y', fma(z,z', w*w'))) with w' = 1 for the
+            // origin (w*1 is exact) and w' = 0 for the direction (adds a zero: only the sign of
+            // an exact zero could differ, which no comparison below can see).
+            lox = __builtin_fmaf(r0.x, o.x, __builtin_fmaf(r0.y, o.y, __builtin_fmaf(r0.z, o.z, r0.w)));
+            loy = __builtin_fmaf(r1.x, o.x, __builtin_fmaf(r1.y, o.y, __builtin_fmaf(r1.z, o.z, r1.w)));
+            loz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
+            ldx = __builtin_fmaf(r0.x, d.x, __builtin_fmaf(r0.y, d.y, r0.z * d.z));
+            ldy = __builtin_fmaf(r1.x, d.x, __builtin_fmaf(r1.y, d.y, r1.z * d.z));
+            ldz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
+        } else {
+            // DotProduct(Vector4): x*x' + y*y' + z*z' + w*w', left to right (math_vector.h:341-343).
+            lox = r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w;
+            loy = r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w;
+            loz = r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w;
+            ldx = r0.x * d.x + r0.y * d.y + r0.z * d.z;
+            ldy = r1.x * d.x + r1.y * d.y + r1.z * d.z;
+            ldz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
+        }
+        float t = (-loz) / ldz;
+        float hx = lox + ldx * t;
+        float hy = loy + ldy * t;
+        bool inside = (hx <= 1.0f) & (hx >= -1.0f) & (hy <= 1.0f) & (hy >= -1.0f);
+        bool closer = t < best_t;
+        if (MIXED && IMODE == RT_INTERSECT_WIDE8) {
+            // A sphere and a rectangle at exactly the same t: the reference keeps the lower
+            // AVX lane, and within one lane the sphere, which it tested first.
+            uint32_t lane = sv.u[sv.off_rects + RECT_WORDS * k + 15] >> TAG_LANE_SHIFT;
+            closer = closer | ((t == best_t) & (lane < best_lane));
+        }
+        if (inside & closer & (t > min_hit)) {
+            best_t = t;
+            best_id = 1 + sv.n_planes + sv.n_spheres + k;
+            if (MIXED) best_lane = 0;
+        }
+    }
+}
+
+struct Hit { V3 normal; uint32_t material; };
+
+// Normal and material of the winning primitive, as the reference computes them
+// at the moment it accepts the hit.
+template <int IMODE>
+__device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id, float t, V3 o, V3 d) {
+    Hit h;
+    uint32_t id = best_id - 1;
+    if (id < sv.n_planes) {
+        const float* pl = sv.f + sv.off_planes + PLANE_WORDS * id;
+        h.normal = load3(pl);
+        h.material = sv.u[sv.off_planes + PLANE_WORDS * id + 4];
+    } else if (id < sv.n_planes + sv.n_spheres) {
+        uint32_t k = id - sv.n_planes;
+        const float4 sp = *reinterpret_cast<const float4*>(sv.f + sv.off_spheres + SPHERE_WORDS * k);
+        V3 c = mk(sp.x, sp.y, sp.z);
+        if (IMODE == RT_INTERSECT_WIDE8) {
+            // main.cpp:86-87: FMulAdd(d, t, o) - c, scaled by the reciprocal square root of its
+            // fma-chain length.  The reference's factor is the x86 rsqrt approximation
+            // (simd_avx2.h:139-144, relative error <= 1.5 * 2^-12, hardware specific); this is the
+            // correctly rounded 1 / sqrt.
+            V3 v = mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)) - c;
+            float f = 1.0f / __builtin_sqrtf(dot_fma(v, v));
+            h.normal = mk(v.x * f, v.y * f, v.z * f);
+        } else {
+            V3 hp = o + d * t;                 // main.cpp:203-204
+            h.normal = normalize(hp - c);
+        }
+        h.material = sv.u[sv.off_tags + k] & TAG_MATERIAL_MASK;
+    } else {
+        uint32_t k = id - sv.n_planes - sv.n_spheres;
+        const float4 tail = *reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_WORDS * k + 12);
+        V3 n = mk(tail.x, tail.y, tail.z);
+        float dp = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(n, d) : dot(n, d);
+        h.normal = dp > 0.0f ? -n : n;          // two-sided (main.cpp:118-126, 228-236)
+        h.material = __float_as_uint(tail.w) & TAG_MATERIAL_MASK;
+    }
+    return h;
+}
+
+// math_util.h:52-79.  inv_ri is the narrowed double quotient 1.0 / ri.
+__device__ __forceinline__ bool refract(V3 incident, V3 normal, float ri, float inv_ri, V3& out) {
+    float cos_i = clampf(-1.0f, dot(incident, normal), 1.0f);
+    V3 hit_normal = normal;
+    float ratio;
+    if (cos_i < 0) {
+        cos_i = -cos_i;
+        ratio = inv_ri;
+    } else {
+        hit_normal = -normal;
+        ratio = ri;
+    }
+    float discriminant = 1 - ratio * ratio * (1 - cos_i * cos_i);
+    if (discriminant < 0) return false;
+    out = incident * ratio + hit_normal * (ratio * cos_i - __builtin_sqrtf(discriminant));
+    return true;
+}
+
+// math_util.h:81-93.  powf(x, 5) is evaluated as a double product and rounded once.
+__device__ __forceinline__ float schlick(V3 incident, V3 normal, float r0) {
+    float cos_i = clampf(-1.0f, dot(incident, normal), 1.0f);
+    float cosine = cos_i > 0 ? cos_i : -cos_i;
+    double x = (double)(1 - cosine);
+    double x2 = x * x;
+    float p5 = (float)(x2 * x2 * x);
+    return r0 + (1 - r0) * p5;
+}
+
+__device__ __forceinline__ void emit_pixel(const KernelParams& p, V3 sum, size_t index,
+                                           uint32_t* pixels, float* radiance) {
+    float n = (float)p.spp;
+    V3 mean = mk(sum.x / n, sum.y / n, sum.z / n);   // color / sampleSize (main.cpp:393)
+    if (pixels) pixels[index] = pack_srgb(mean);
+    if (radiance) {
+        V3 out = p.output_sum ? sum : mean;
+        radiance[3 * index + 0] = out.x;
+        radiance[3 * index + 1] = out.y;
+        radiance[3 * index + 2] = out.z;
+    }
+}
+
+constexpr int BLOCK_THREADS = 256;
+
+template <int IMODE, int RMODE, bool MIXED>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
+                                                               uint32_t* __restrict__ pixels,
+                                                               float* __restrict__ radiance,
+                                                               unsigned long long* __restrict__ rays) {
+    extern __shared__ uint4 lds_image[];
+    for (uint32_t i = threadIdx.x; i < p.scene_words / 4; i += BLOCK_THREADS) lds_image[i] = scene_image[i];
+    __syncthreads();
+
+    SceneView sv;
+    sv.f = reinterpret_cast<const float*>(lds_image);
+    sv.u = reinterpret_cast<const uint32_t*>(lds_image);
+    sv.n_planes = sv.u[H_NPLANES]; sv.n_spheres = sv.u[H_NSPHERES]; sv.n_rects = sv.u[H_NRECTS];
+    sv.off_planes = sv.u[H_OFF_PLANES]; sv.off_spheres = sv.u[H_OFF_SPHERES]; sv.off_tags = sv.u[H_OFF_SPHERE_TAGS];
+    sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
+
+    const V3 cam_pos = load3(p.cam_pos), cam_x = load3(p.cam_x), cam_y = load3(p.cam_y);
+    const V3 film_center = load3(p.film_center);
+
+    const uint32_t gid = blockIdx.x * BLOCK_THREADS + threadIdx.x;
+
+    // ---- this lane's stream and its list of samples --------------------------------
+    uint32_t state = 1;
+    uint32_t x = 0, ly = 0, ly_end = 0;   // current pixel (local row) and end of the lane's rows
+    uint32_t samples_left = 0;            // samples still to START in the current pixel
+    bool has_pixel = false;               // the lane still owns an unfinished pixel
+    bool pixel_valid = false;             // PIXEL: lane maps to a pixel inside the image
+
+    if (RMODE == RT_RNG_ROW_SERIAL) {
+        if (gid < p.order_count) {
+            ly = gid * p.rows_per_order;
+            ly_end = min(ly + p.rows_per_order, p.local_rows);
+            uint32_t start_row = global_row(p, ly);
+            uint32_t end_row = global_row(p, ly_end - 1) + 1;
+            state = p.seed_constant * (start_row + end_row * 36u);   // main.cpp:370
+            has_pixel = true;
+            samples_left = p.spp;
+        }
+    } else {
+        const uint32_t wave = gid >> 6, lane = gid & 63u;
+        const uint32_t q = lane / p.lanes_per_pixel, b = lane % p.lanes_per_pixel;
+        const uint32_t tile_x = wave % p.tiles_x, tile_y = wave / p.tiles_x;
+        x = tile_x * p.tile_w + q % p.tile_w;
+        ly = tile_y * p.tile_h + q / p.tile_w;
+        pixel_valid = (tile_y < p.tiles_y) && (x < p.width) && (ly < p.local_rows);
+        if (pixel_valid) {
+            state = pixel_stream_seed(p.seed_constant, x, global_row(p, ly), p.batch_offset + b);
+            has_pixel = true;
+            samples_left = p.samples_per_lane;
+        }
+    }
+
+    float film_x = 0.0f, film_y = 0.0f;
+    if (has_pixel) {
+        film_y = ((float)(int32_t)global_row(p, ly) / (float)(int32_t)p.height) * -2.0f + 1.0f;   // main.cpp:375
+        film_x = (((float)(int32_t)x / (float)(int32_t)p.width) * 2.0f - 1.0f);                   // main.cpp:377
+    }
+
+    V3 pixel_sum = mk(0.0f, 0.0f, 0.0f);
+    V3 ro = cam_pos, rd = mk(0.0f, 0.0f, 1.0f), attenuation = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+    uint32_t bounce = 0;
+    bool in_path = false;
+    unsigned long long ray_count = 0;
+    uint32_t pixel_rays = 0;
+
+    while (true) {
+        // ---- start the next sample of this lane's list (main.cpp:381-388) ----------
+        if (!in_path && has_pixel) {
+            if (samples_left == 0) {
+                // every sample of the pixel has finished
+                if (RMODE == RT_RNG_ROW_SERIAL) {
+                    emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
+                    ray_count += pixel_rays;
+                    pixel_rays = 0;
+                    pixel_sum = mk(0.0f, 0.0f, 0.0f);
+                    if (++x == p.width) {
+                        x = 0;
+                        ++ly;
+                        if (ly < ly_end)
+                            film_y = ((float)(int32_t)global_row(p, ly) / (float)(int32_t)p.height) * -2.0f + 1.0f;
+                    }
+                    if (ly < ly_end) {
+                        film_x = (((float)(int32_t)x / (float)(int32_t)p.width) * 2.0f - 1.0f);
+                        samples_left = p.spp;
+                    } else {
+                        has_pixel = false;
+                    }
+                } else {
+                    has_pixel = false;   // the pixel is written after the loop (cross-lane sum)
+                }
+            }
+            if (has_pixel) {
+                --samples_left;
+                float off_x = film_x + random_bilateral(state) * p.pixel_w;
+                float off_y = film_y + random_bilateral(state) * p.pixel_h;
+                V3 film_pos = film_center + cam_x * off_x * p.half_w + cam_y * p.half_h * off_y;
+                ro = cam_pos;
+                rd = normalize(film_pos - cam_pos);
+                attenuation = mk(1.0f, 1.0f, 1.0f);
+                result = mk(0.0f, 0.0f, 0.0f);
+                bounce = 0;
+                in_path = true;
+            }
+        }
+        if (__ballot(in_path) == 0ull) break;   // no lane of the wave has a path to extend
+
+        // ---- one bounce (main.cpp:275-330) -------------------------------------------
+        if (in_path) {
+            float t;
+            uint32_t best_id;
+            intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol, t, best_id);
+            ++pixel_rays;
+            ++bounce;
+            if (best_id != 0) {
+                Hit h = resolve_hit<IMODE>(sv, best_id, t, ro, rd);
+                const float4* m = reinterpret_cast<const float4*>(sv.f + sv.off_mats + MAT_WORDS * h.material);
+                const float4 m0 = m[0], m1 = m[1], m2 = m[2];   // color ri | emit reflection | 1/ri r0
+                result = result + attenuation * mk(m1.x, m1.y, m1.z);
+                attenuation = attenuation * mk(m0.x, m0.y, m0.z);
+                ro = ro + rd * t;
+
+                V3 n = h.normal;
+                V3 mirror = rd - n * dot(n, rd) * 2.0f;
+                // g++ evaluates the constructor arguments right to left: z, y, x (main.cpp:291-294).
+                float rz = random_bilateral(state);
+                float ry = random_bilateral(state);
+                float rx = random_bilateral(state);
+                V3 random_bounce = n + mk(rx, ry, rz);
+                float refl = m1.w;
+                V3 reflected = normalize(random_bounce * (1.0f - refl) + mirror * refl);   // Lerp, math_util.h:24-26
+
+                float fresnel = 1.0f;
+                V3 refracted = reflected;
+                if (m0.w != 0.0f) {
+                    if (refract(rd, n, m0.w, m2.x, refracted)) {
+                        refracted = normalize(refracted);
+                        fresnel = schlick(rd, n, m2.y);
+                    }
+                }
+                rd = (random_unilateral(state) <= fresnel) ? reflected : refracted;
+                if (bounce >= p.max_bounces) in_path = false;
+            } else {
+                const float4 sky = *reinterpret_cast<const float4*>(sv.f + sv.off_mats + 4);   // materials[0].emit
+                result = result + attenuation * mk(sky.x, sky.y, sky.z);
+                in_path = false;
+            }
+            if (!in_path) pixel_sum = pixel_sum + result;   // color += RaytraceWorld(...) (main.cpp:390)
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------
+    ray_count += pixel_rays;
+    if (RMODE == RT_RNG_PIXEL) {
+        // Pairwise tree over the lanes_per_pixel partial sums of each pixel.
+        for (uint32_t stride = 1; stride < p.lanes_per_pixel; stride <<= 1) {
+            float sx = __shfl_down(pixel_sum.x, stride);
+            float sy = __shfl_down(pixel_sum.y, stride);
+            float sz = __shfl_down(pixel_sum.z, stride);
+            if (((threadIdx.x % p.lanes_per_pixel) & (2 * stride - 1)) == 0) pixel_sum = pixel_sum + mk(sx, sy, sz);
+        }
+        if (pixel_valid && (threadIdx.x % p.lanes_per_pixel) == 0)
+            emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
+    }
+    // Ray counter: one 64-bit atomic per wave (main.cpp:397).
+    for (int offset = 32; offset > 0; offset >>= 1) ray_count += __shfl_down(ray_count, offset);
+    if ((threadIdx.x & 63) == 0 && ray_count != 0 && rays) atomicAdd(rays, ray_count);
+}
+
+// Tonemap + pack of an accumulated sum (epilogue of main.cpp:393 on its own).
+__global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const float* __restrict__ sum, uint64_t pixel_count,
+                                                                float total_samples, uint32_t* __restrict__ pixels,
+                                                                float* __restrict__ mean_out) {
+    uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    if (i >= pixel_count) return;
+    V3 mean = mk(sum[3 * i] / total_samples, sum[3 * i + 1] / total_samples, sum[3 * i + 2] / total_samples);
+    if (pixels) pixels[i] = pack_srgb(mean);
+    if (mean_out) { mean_out[3 * i] = mean.x; mean_out[3 * i + 1] = mean.y; mean_out[3 * i + 2] = mean.z; }
+}
+
+}  // namespace rt

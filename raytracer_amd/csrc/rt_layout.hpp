@@ -1,0 +1,112 @@
+// Device scene image: the word layout a workgroup copies into LDS, and the host
+// code that packs it from the caller's AoS arrays (rt_world, include/rt_hip.h).
+//
+// One image per intersection mode, each self-contained (header + sections), so
+// the kernel stages it with a flat 16-byte copy:
+//
+//   header   16 words  counts and section offsets (in words)
+//   planes    8 words  nx ny nz d | material 0 0 0
+//   spheres   4 words  cx cy cz r*r                      (one ds_read_b128 per test)
+//   sph.tag   1 word   material | wide_lane << 24
+//   rects    16 words  rows 0..2 of the inverse transform (3 x 4), nx ny nz, material | wide_lane << 24
+//   mats     12 words  color[3] ri emit[3] reflection | 1/ri r0 0 0
+//
+// RT_INTERSECT_WIDE8 order: the reference tests primitives 8 at a time, lane j of
+// group g being primitive 8g+j, keeps a running closest hit PER LANE and finally
+// takes the first strictly smaller lane (main.cpp:60-154).  The winner is therefore
+// the hit with the smallest t, ties going to the lowest lane j, then the lowest
+// group g.  Storing the primitives sorted by (j, g) turns that into a plain
+// first-strictly-smaller scan.  RT_INTERSECT_SCALAR keeps the caller's order
+// (main.cpp:182-239).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+
+namespace rt {
+
+enum : uint32_t {
+    H_NPLANES = 0, H_NSPHERES, H_NRECTS, H_NMATS,
+    H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS,
+    H_WORDS = 16
+};
+
+constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_WORDS = 16, MAT_WORDS = 12;
+constexpr uint32_t WIDE_LANES = 8;        // simd.h:17
+constexpr uint32_t TAG_LANE_SHIFT = 24;   // tag = material | lane << 24
+constexpr uint32_t TAG_MATERIAL_MASK = 0x00FFFFFFu;
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// Indices 0..n-1 sorted by (i % 8, i / 8).
+inline std::vector<uint32_t> wide_order(uint32_t n) {
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    for (uint32_t j = 0; j < WIDE_LANES; ++j)
+        for (uint32_t i = j; i < n; i += WIDE_LANES) order.push_back(i);
+    return order;
+}
+
+inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
+    auto round4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+    uint32_t off_planes = H_WORDS;
+    uint32_t off_spheres = off_planes + PLANE_WORDS * w.plane_count;
+    uint32_t off_tags = off_spheres + SPHERE_WORDS * w.sphere_count;
+    uint32_t off_rects = round4(off_tags + w.sphere_count);
+    uint32_t off_mats = off_rects + RECT_WORDS * w.rectangle_count;
+    uint32_t total = round4(off_mats + MAT_WORDS * w.material_count);
+
+    std::vector<uint32_t> img(total, 0u);
+    img[H_NPLANES] = w.plane_count; img[H_NSPHERES] = w.sphere_count;
+    img[H_NRECTS] = w.rectangle_count; img[H_NMATS] = w.material_count;
+    img[H_OFF_PLANES] = off_planes; img[H_OFF_SPHERES] = off_spheres; img[H_OFF_SPHERE_TAGS] = off_tags;
+    img[H_OFF_RECTS] = off_rects; img[H_OFF_MATS] = off_mats; img[H_TOTAL_WORDS] = total;
+
+    for (uint32_t i = 0; i < w.plane_count; ++i) {
+        const rt_plane& p = w.planes[i];
+        uint32_t* q = &img[off_planes + PLANE_WORDS * i];
+        q[0] = f2u(p.normal[0]); q[1] = f2u(p.normal[1]); q[2] = f2u(p.normal[2]); q[3] = f2u(p.d);
+        q[4] = p.material_index;
+    }
+
+    std::vector<uint32_t> sphere_order = wide ? wide_order(w.sphere_count) : std::vector<uint32_t>();
+    for (uint32_t k = 0; k < w.sphere_count; ++k) {
+        uint32_t i = wide ? sphere_order[k] : k;
+        const rt_sphere& s = w.spheres[i];
+        uint32_t* q = &img[off_spheres + SPHERE_WORDS * k];
+        q[0] = f2u(s.position[0]); q[1] = f2u(s.position[1]); q[2] = f2u(s.position[2]);
+        q[3] = f2u(s.radius * s.radius);   // scene.h:274 / main.cpp:187: rounded once, then used
+        img[off_tags + k] = s.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
+    }
+
+    std::vector<uint32_t> rect_order = wide ? wide_order(w.rectangle_count) : std::vector<uint32_t>();
+    for (uint32_t k = 0; k < w.rectangle_count; ++k) {
+        uint32_t i = wide ? rect_order[k] : k;
+        const rt_rectangle& r = w.rectangles[i];
+        uint32_t* q = &img[off_rects + RECT_WORDS * k];
+        for (int row = 0; row < 3; ++row)          // the 4th row only feeds the unused w component
+            for (int col = 0; col < 4; ++col) q[row * 4 + col] = f2u(r.inverse_transform[row][col]);
+        q[12] = f2u(r.normal[0]); q[13] = f2u(r.normal[1]); q[14] = f2u(r.normal[2]);
+        q[15] = r.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
+    }
+
+    for (uint32_t i = 0; i < w.material_count; ++i) {
+        const rt_material& m = w.materials[i];
+        uint32_t* q = &img[off_mats + MAT_WORDS * i];
+        q[0] = f2u(m.color[0]); q[1] = f2u(m.color[1]); q[2] = f2u(m.color[2]); q[3] = f2u(m.refractive_index);
+        q[4] = f2u(m.emit_color[0]); q[5] = f2u(m.emit_color[1]); q[6] = f2u(m.emit_color[2]); q[7] = f2u(m.reflection);
+        float ri = m.refractive_index;
+        // Refract: `1.0 / refractiveIndex` is a double division narrowed to float (math_util.h:62).
+        float inv_ri = ri != 0.0f ? (float)(1.0 / (double)ri) : 0.0f;
+        // Schlick: r0 = ((1 - ri) / (1 + ri))^2 in float (math_util.h:90-91).
+        float r0 = (1 - ri) / (1 + ri);
+        r0 = r0 * r0;
+        q[8] = f2u(inv_ri); q[9] = f2u(r0);
+    }
+    return img;
+}
+
+}  // namespace rt
