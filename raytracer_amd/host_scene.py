@@ -1,0 +1,70 @@
+"""ctypes access to librt_host.so: the C++ scene builders and the BMP writer."""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+from . import scene_io
+from .binding import World
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "librt_host.so"
+
+EXPORTS = ("rth_world_create", "rth_world_destroy", "rth_world_view", "rth_world_write", "rth_write_bmp")
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/host`")
+        L = C.CDLL(str(LIB_PATH))
+        L.rth_world_create.restype = C.c_void_p
+        L.rth_world_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64]
+        L.rth_world_destroy.restype = None
+        L.rth_world_destroy.argtypes = [C.c_void_p]
+        L.rth_world_view.restype = None
+        L.rth_world_view.argtypes = [C.c_void_p, C.POINTER(World)]
+        L.rth_world_write.restype = C.c_int
+        L.rth_world_write.argtypes = [C.c_void_p, C.c_char_p]
+        L.rth_write_bmp.restype = C.c_int
+        L.rth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _copy(ptr, dtype, count):
+    if not count:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (dtype.itemsize * count)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+def build_scene(name: str, count: int = 0, seed: int = 1) -> scene_io.Scene:
+    """Builds a scene with the C++ builders: "cornell", "spheres", "random_spheres", "glass_spheres" or an RTSC path."""
+    L = load_library()
+    h = L.rth_world_create(str(name).encode(), count, seed)
+    if not h:
+        raise ValueError(f"unknown scene or unreadable scene file: {name!r}")
+    try:
+        v = World()
+        L.rth_world_view(h, C.byref(v))
+        return scene_io.Scene(
+            _copy(v.materials, scene_io.MATERIAL, v.material_count),
+            _copy(v.planes, scene_io.PLANE, v.plane_count),
+            _copy(v.spheres, scene_io.SPHERE, v.sphere_count),
+            _copy(v.rectangles, scene_io.RECTANGLE, v.rectangle_count),
+            _copy(v.camera, scene_io.CAMERA, 1))
+    finally:
+        L.rth_world_destroy(h)
+
+
+def write_bmp(path, pixels: np.ndarray) -> None:
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint32)
+    h, w = pixels.shape
+    if load_library().rth_write_bmp(str(path).encode(), pixels.ctypes.data_as(C.c_void_p), w, h) != 0:
+        raise OSError(f"cannot write {path}")
