@@ -63,6 +63,14 @@ __device__ __forceinline__ V3 normalize(V3 v) {
 }
 __device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
 
+// Two independent floats in one 64-bit register pair: one v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 does the work of two scalar instructions, each element rounded exactly as
+// the scalar operation would be.
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 f2(float a, float b) { F2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ F2 splat(float a) { return f2(a, a); }
+__device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // math_util.h:32-50.  (float)U32Max is 2^32, so the division is an exact scaling.
 __device__ __forceinline__ uint32_t xorshift32(uint32_t& s) {
     uint32_t x = s;
@@ -177,45 +185,53 @@ __device__ __forceinline__ void intersect_world(const SceneView& sv, V3 o, V3 d,
     }
 
     // Rectangles (main.cpp:96-129 / 212-239): ray into the rectangle's frame, hit the
-    // z = 0 plane, test against the unit square.
-    for (uint32_t k = 0; k < sv.n_rects; ++k) {
-        const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_WORDS * k);
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        float lox, loy, loz, ldx, ldy, ldz;
+    // z = 0 plane, test against the unit square.  Two rectangles (A, B) per step: rows 0 and 1
+    // of each matrix ride in the two halves of packed registers, and so do the two row-2 dot
+    // products of the pair.
+    const F2 ox2 = splat(o.x), oy2 = splat(o.y), oz2 = splat(o.z);
+    const F2 dx2 = splat(d.x), dy2 = splat(d.y), dz2 = splat(d.z);
+    const uint32_t rect_base = 1 + sv.n_planes + sv.n_spheres;
+    for (uint32_t pair = 0; pair < sv.n_rects / 2; ++pair) {
+        const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
+        const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3], z01 = rec[4], z23 = rec[5];
+        F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
         if (IMODE == RT_INTERSECT_WIDE8) {
             // DotProduct(LaneVector4): fma(x,x', fma(y,y', fma(z,z', w*w'))) with w' = 1 for the
             // origin (w*1 is exact) and w' = 0 for the direction (adds a zero: only the sign of
             // an exact zero could differ, which no comparison below can see).
-            lox = __builtin_fmaf(r0.x, o.x, __builtin_fmaf(r0.y, o.y, __builtin_fmaf(r0.z, o.z, r0.w)));
-            loy = __builtin_fmaf(r1.x, o.x, __builtin_fmaf(r1.y, o.y, __builtin_fmaf(r1.z, o.z, r1.w)));
-            loz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
-            ldx = __builtin_fmaf(r0.x, d.x, __builtin_fmaf(r0.y, d.y, r0.z * d.z));
-            ldy = __builtin_fmaf(r1.x, d.x, __builtin_fmaf(r1.y, d.y, r1.z * d.z));
-            ldz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
+            a_lo = fma2(f2(a01.x, a01.y), ox2, fma2(f2(a01.z, a01.w), oy2, fma2(f2(a23.x, a23.y), oz2, f2(a23.z, a23.w))));
+            b_lo = fma2(f2(b01.x, b01.y), ox2, fma2(f2(b01.z, b01.w), oy2, fma2(f2(b23.x, b23.y), oz2, f2(b23.z, b23.w))));
+            z_lo = fma2(f2(z01.x, z01.y), ox2, fma2(f2(z01.z, z01.w), oy2, fma2(f2(z23.x, z23.y), oz2, f2(z23.z, z23.w))));
+            a_ld = fma2(f2(a01.x, a01.y), dx2, fma2(f2(a01.z, a01.w), dy2, f2(a23.x, a23.y) * dz2));
+            b_ld = fma2(f2(b01.x, b01.y), dx2, fma2(f2(b01.z, b01.w), dy2, f2(b23.x, b23.y) * dz2));
+            z_ld = fma2(f2(z01.x, z01.y), dx2, fma2(f2(z01.z, z01.w), dy2, f2(z23.x, z23.y) * dz2));
         } else {
             // DotProduct(Vector4): x*x' + y*y' + z*z' + w*w', left to right (math_vector.h:341-343).
-            lox = r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w;
-            loy = r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w;
-            loz = r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w;
-            ldx = r0.x * d.x + r0.y * d.y + r0.z * d.z;
-            ldy = r1.x * d.x + r1.y * d.y + r1.z * d.z;
-            ldz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
+            a_lo = f2(a01.x, a01.y) * ox2 + f2(a01.z, a01.w) * oy2 + f2(a23.x, a23.y) * oz2 + f2(a23.z, a23.w);
+            b_lo = f2(b01.x, b01.y) * ox2 + f2(b01.z, b01.w) * oy2 + f2(b23.x, b23.y) * oz2 + f2(b23.z, b23.w);
+            z_lo = f2(z01.x, z01.y) * ox2 + f2(z01.z, z01.w) * oy2 + f2(z23.x, z23.y) * oz2 + f2(z23.z, z23.w);
+            a_ld = f2(a01.x, a01.y) * dx2 + f2(a01.z, a01.w) * dy2 + f2(a23.x, a23.y) * dz2;
+            b_ld = f2(b01.x, b01.y) * dx2 + f2(b01.z, b01.w) * dy2 + f2(b23.x, b23.y) * dz2;
+            z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
         }
-        float t = (-loz) / ldz;
-        float hx = lox + ldx * t;
-        float hy = loy + ldy * t;
-        bool inside = (hx <= 1.0f) & (hx >= -1.0f) & (hy <= 1.0f) & (hy >= -1.0f);
-        bool closer = t < best_t;
-        if (MIXED && IMODE == RT_INTERSECT_WIDE8) {
-            // A sphere and a rectangle at exactly the same t: the reference keeps the lower
-            // AVX lane, and within one lane the sphere, which it tested first.
-            uint32_t lane = sv.u[sv.off_rects + RECT_WORDS * k + 15] >> TAG_LANE_SHIFT;
-            closer = closer | ((t == best_t) & (lane < best_lane));
-        }
-        if (inside & closer & (t > min_hit)) {
-            best_t = t;
-            best_id = 1 + sv.n_planes + sv.n_spheres + k;
-            if (MIXED) best_lane = 0;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const float loz = which ? z_lo.y : z_lo.x, ldz = which ? z_ld.y : z_ld.x;
+            const F2 lo = which ? b_lo : a_lo, ld = which ? b_ld : a_ld;
+            const float t = (-loz) / ldz;
+            const F2 h = lo + ld * splat(t);
+            bool closer = t < best_t;
+            if (MIXED && IMODE == RT_INTERSECT_WIDE8) {
+                // A sphere and a rectangle at exactly the same t: the reference keeps the lower
+                // AVX lane, and within one lane the sphere, which it tested first.
+                uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
+                closer = closer || (t == best_t && lane < best_lane);
+            }
+            if (__builtin_fabsf(h.x) <= 1.0f && __builtin_fabsf(h.y) <= 1.0f && closer && t > min_hit) {
+                best_t = t;
+                best_id = rect_base + 2 * pair + which;
+                if (MIXED) best_lane = 0;
+            }
         }
     }
 }
@@ -251,7 +267,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
         h.material = sv.u[sv.off_tags + k] & TAG_MATERIAL_MASK;
     } else {
         uint32_t k = id - sv.n_planes - sv.n_spheres;
-        const float4 tail = *reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_WORDS * k + 12);
+        const float4 tail = *reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * (k >> 1) + 24 + 4 * (k & 1));
         V3 n = mk(tail.x, tail.y, tail.z);
         float dp = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(n, d) : dot(n, d);
         h.normal = dp > 0.0f ? -n : n;          // two-sided (main.cpp:118-126, 228-236)

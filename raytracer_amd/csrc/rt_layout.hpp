@@ -8,7 +8,12 @@
 //   planes    8 words  nx ny nz d | material 0 0 0
 //   spheres   4 words  cx cy cz r*r                      (one ds_read_b128 per test)
 //   sph.tag   1 word   material | wide_lane << 24
-//   rects    16 words  rows 0..2 of the inverse transform (3 x 4), nx ny nz, material | wide_lane << 24
+//   rects    32 words per PAIR of rectangles (A, B), laid out for packed-FP32 arithmetic:
+//              A.r0x A.r1x A.r0y A.r1y | A.r0z A.r1z A.r0w A.r1w      rows 0,1 of A's inverse transform, interleaved
+//              B.r0x B.r1x B.r0y B.r1y | B.r0z B.r1z B.r0w B.r1w      same for B
+//              A.r2x B.r2x A.r2y B.r2y | A.r2z B.r2z A.r2w B.r2w      row 2 of A and of B, interleaved
+//              A.nx A.ny A.nz A.tag    | B.nx B.ny B.nz B.tag         tag = material | wide_lane << 24
+//            an odd count is padded with an all-zero rectangle (t = -0/0 = NaN: never hit)
 //   mats     12 words  color[3] ri emit[3] reflection | 1/ri r0 0 0
 //
 // RT_INTERSECT_WIDE8 order: the reference tests primitives 8 at a time, lane j of
@@ -34,7 +39,7 @@ enum : uint32_t {
     H_WORDS = 16
 };
 
-constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_WORDS = 16, MAT_WORDS = 12;
+constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_PAIR_WORDS = 32, MAT_WORDS = 12;
 constexpr uint32_t WIDE_LANES = 8;        // simd.h:17
 constexpr uint32_t TAG_LANE_SHIFT = 24;   // tag = material | lane << 24
 constexpr uint32_t TAG_MATERIAL_MASK = 0x00FFFFFFu;
@@ -56,12 +61,13 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
     uint32_t off_spheres = off_planes + PLANE_WORDS * w.plane_count;
     uint32_t off_tags = off_spheres + SPHERE_WORDS * w.sphere_count;
     uint32_t off_rects = round4(off_tags + w.sphere_count);
-    uint32_t off_mats = off_rects + RECT_WORDS * w.rectangle_count;
+    const uint32_t rect_slots = (w.rectangle_count + 1u) & ~1u;   // padded to whole pairs
+    uint32_t off_mats = off_rects + RECT_PAIR_WORDS * (rect_slots / 2);
     uint32_t total = round4(off_mats + MAT_WORDS * w.material_count);
 
     std::vector<uint32_t> img(total, 0u);
     img[H_NPLANES] = w.plane_count; img[H_NSPHERES] = w.sphere_count;
-    img[H_NRECTS] = w.rectangle_count; img[H_NMATS] = w.material_count;
+    img[H_NRECTS] = rect_slots; img[H_NMATS] = w.material_count;
     img[H_OFF_PLANES] = off_planes; img[H_OFF_SPHERES] = off_spheres; img[H_OFF_SPHERE_TAGS] = off_tags;
     img[H_OFF_RECTS] = off_rects; img[H_OFF_MATS] = off_mats; img[H_TOTAL_WORDS] = total;
 
@@ -86,11 +92,18 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
     for (uint32_t k = 0; k < w.rectangle_count; ++k) {
         uint32_t i = wide ? rect_order[k] : k;
         const rt_rectangle& r = w.rectangles[i];
-        uint32_t* q = &img[off_rects + RECT_WORDS * k];
-        for (int row = 0; row < 3; ++row)          // the 4th row only feeds the unused w component
-            for (int col = 0; col < 4; ++col) q[row * 4 + col] = f2u(r.inverse_transform[row][col]);
-        q[12] = f2u(r.normal[0]); q[13] = f2u(r.normal[1]); q[14] = f2u(r.normal[2]);
-        q[15] = r.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
+        uint32_t* q = &img[off_rects + RECT_PAIR_WORDS * (k / 2)];
+        const uint32_t which = k & 1u;
+        const auto& m = r.inverse_transform;             // the 4th row only feeds the unused w component
+        for (int col = 0; col < 4; ++col) {
+            uint32_t* rows01 = q + 8 * which + 4 * (col / 2) + 2 * (col % 2);
+            rows01[0] = f2u(m[0][col]);
+            rows01[1] = f2u(m[1][col]);
+            q[16 + 4 * (col / 2) + 2 * (col % 2) + which] = f2u(m[2][col]);
+        }
+        uint32_t* tail = q + 24 + 4 * which;
+        tail[0] = f2u(r.normal[0]); tail[1] = f2u(r.normal[1]); tail[2] = f2u(r.normal[2]);
+        tail[3] = r.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
     }
 
     for (uint32_t i = 0; i < w.material_count; ++i) {
