@@ -314,7 +314,7 @@ static inline float hw_rsqrt(float v) { /* _mm256_rsqrt_ps, one lane (simd_avx2.
     return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(v)));
 }
 
-static int intersect_wide(const rto_scene* s, float min_hit, float plane_tol, v3 o, v3 d,
+static int intersect_wide(const rto_scene* s, int ieee_rsqrt, float min_hit, float plane_tol, v3 o, v3 d,
                           float* t_out, uint32_t* mat_out, v3* n_out) {
     float closest = FLT_MAX;
     uint32_t hit_mat = 0;
@@ -359,7 +359,8 @@ static int intersect_wide(const rto_scene* s, float min_hit, float plane_tol, v3
                 lane_mat[j] = blk[4 * LANES + j];
                 float hx = fmaf(d.x, hit, o.x), hy = fmaf(d.y, hit, o.y), hz = fmaf(d.z, hit, o.z);
                 float vx = hx - cx, vy = hy - cy, vz = hz - cz;
-                float f = hw_rsqrt(lane_dot3(vx, vy, vz, vx, vy, vz));
+                float len2 = lane_dot3(vx, vy, vz, vx, vy, vz);
+                float f = ieee_rsqrt ? 1.0f / sqrtf(len2) : hw_rsqrt(len2);
                 lane_nx[j] = vx * f; lane_ny[j] = vy * f; lane_nz[j] = vz * f;
                 any_hit = 1;
             }
@@ -410,7 +411,7 @@ static inline int intersect(const rto_scene* s, int mode, float min_hit, float p
                             float* t, uint32_t* mat, v3* n) {
     if (mode == RTO_INTERSECT_SCALAR) return intersect_scalar(s, min_hit, plane_tol, o, d, t, mat, n);
     if (mode == RTO_INTERSECT_WIDE8_AVX2) return rto_intersect_wide_avx2(s, min_hit, plane_tol, o, d, t, mat, n);
-    return intersect_wide(s, min_hit, plane_tol, o, d, t, mat, n);
+    return intersect_wide(s, mode == RTO_INTERSECT_WIDE8_IEEE, min_hit, plane_tol, o, d, t, mat, n);
 }
 
 int rto_intersect(const rto_scene* scene, int intersect_mode, float min_hit, float plane_tol,

@@ -40,7 +40,11 @@ typedef struct { float position[3]; float z_axis[3]; float y_axis[3]; float x_ax
 
 typedef struct rto_scene rto_scene;
 
-enum { RTO_INTERSECT_WIDE8 = 0, RTO_INTERSECT_SCALAR = 1, RTO_INTERSECT_WIDE8_AVX2 = 2 };
+/* WIDE8 / WIDE8_AVX2 scale sphere normals by the x86 rsqrt approximation, as the reference does
+ * (simd_avx2.h:139-144; hardware specific, relative error <= 1.5 * 2^-12).  WIDE8_IEEE uses the
+ * correctly rounded 1/sqrtf instead and is otherwise identical: it is what the HIP kernels compute,
+ * since no GPU instruction reproduces the x86 approximation. */
+enum { RTO_INTERSECT_WIDE8 = 0, RTO_INTERSECT_SCALAR = 1, RTO_INTERSECT_WIDE8_AVX2 = 2, RTO_INTERSECT_WIDE8_IEEE = 3 };
 enum { RTO_RNG_ROW_SERIAL = 0, RTO_RNG_PIXEL = 1 };
 
 typedef struct {

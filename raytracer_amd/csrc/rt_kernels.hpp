@@ -71,6 +71,26 @@ __device__ __forceinline__ F2 f2(float a, float b) { F2 r; r.x = a; r.y = b; ret
 __device__ __forceinline__ F2 splat(float a) { return f2(a, a); }
 __device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Two correctly rounded quotients a/b at once.  This is the refinement the compiler emits for
+// an IEEE float division (reciprocal estimate, one Newton step on it, quotient, two residual
+// corrections) without its operand pre-scaling and special-case fix-up, so the seven
+// multiply-adds pack two divisions into seven instructions.  It returns the IEEE quotient
+// whenever that scaling would have been the identity: b normal, |a| >= 2^-100 or a == 0, and
+// 2^-100 < |a/b| < 2^96.  Outside that range (a ray parallel to a rectangle's plane, a
+// zero-padded slot) the result is inf, NaN or a value of the true quotient's huge or tiny
+// magnitude; the caller's tests (t > min_hit, t < closest, |h| <= 1) reject all of those just
+// as they reject the IEEE quotient there, given finite matrices of rank 3.
+__device__ __forceinline__ F2 div2(F2 a, F2 b) {
+    F2 y = f2(__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y));
+    F2 e = fma2(-b, y, splat(1.0f));
+    y = fma2(e, y, y);
+    F2 q = a * y;
+    F2 r = fma2(-b, q, a);
+    q = fma2(r, y, q);
+    r = fma2(-b, q, a);
+    return fma2(r, y, q);
+}
+
 // math_util.h:32-50.  (float)U32Max is 2^32, so the division is an exact scaling.
 __device__ __forceinline__ uint32_t xorshift32(uint32_t& s) {
     uint32_t x = s;
@@ -214,11 +234,11 @@ __device__ __forceinline__ void intersect_world(const SceneView& sv, V3 o, V3 d,
             b_ld = f2(b01.x, b01.y) * dx2 + f2(b01.z, b01.w) * dy2 + f2(b23.x, b23.y) * dz2;
             z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
         }
+        const F2 t2 = div2(-z_lo, z_ld);   // t = (-origin'.z) / direction'.z for A and B
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            const float loz = which ? z_lo.y : z_lo.x, ldz = which ? z_ld.y : z_ld.x;
             const F2 lo = which ? b_lo : a_lo, ld = which ? b_ld : a_ld;
-            const float t = (-loz) / ldz;
+            const float t = which ? t2.y : t2.x;
             const F2 h = lo + ld * splat(t);
             bool closer = t < best_t;
             if (MIXED && IMODE == RT_INTERSECT_WIDE8) {

@@ -1,0 +1,131 @@
+"""Multi-GPU composition of renders: one process per GPU, torch.distributed (RCCL on GPUs).
+
+The reference's unit of work is the image row (one WorkOrder per row, main.cpp:433-448) and
+rows never exchange data, so a render shards with no collective on the data path; the only
+exchange is assembling the result on rank 0:
+
+  rows     each rank renders interleaved 8-row bands of the image (band b belongs to rank
+           b mod N: the Cornell box is half black rows, so contiguous slabs would be uneven)
+           and the packed rows are collected with ONE all_gather.
+  samples  each rank renders every pixel with its own sample-batch indices
+           (batch_offset = rank * lanes_per_pixel) and the un-normalised radiance sums are
+           added onto rank 0 with ONE reduce(SUM), then tonemapped there.
+
+The renderer itself is injected (`render` / `resolve` callables working on torch tensors),
+so the same composition runs on GPUs with the HIP library and, in the CPU tests, over gloo.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+BAND_ROWS = 8
+
+
+def band_params(params, rank: int, world_size: int, band_rows: int = BAND_ROWS):
+    """Copy of `params` restricted to the row bands of `rank`."""
+    p = copy.copy(params)
+    if world_size > 1:
+        p.band_rows, p.band_index, p.band_count = band_rows, rank, world_size
+    return p
+
+
+def local_rows(params) -> int:
+    total = params.row_end - params.row_begin
+    if params.band_rows == 0 or params.band_count <= 1:
+        return total
+    bands = (total + params.band_rows - 1) // params.band_rows
+    n = 0
+    for b in range(params.band_index, bands, params.band_count):
+        n += min((b + 1) * params.band_rows, total) - b * params.band_rows
+    return n
+
+
+def global_rows(params) -> list[int]:
+    rows = []
+    for local in range(local_rows(params)):
+        if params.band_rows == 0 or params.band_count <= 1:
+            rows.append(params.row_begin + local)
+        else:
+            band, within = divmod(local, params.band_rows)
+            rows.append(params.row_begin + (band * params.band_count + params.band_index) * params.band_rows + within)
+    return rows
+
+
+def batch_params(params, rank: int, world_size: int, output_sum_flag: int):
+    """Copy of `params` whose sample batches are those of `rank`; asks for the radiance sum."""
+    p = copy.copy(params)
+    p.batch_offset = params.batch_offset + rank * params.lanes_per_pixel
+    p.flags = params.flags | output_sum_flag
+    return p
+
+
+class RowShardedImage:
+    """Buffers and the gather for the `rows` mode.  All ranks hold equal-sized shards (the
+    largest band set), as all_gather requires; rank 0 un-interleaves."""
+
+    def __init__(self, params, rank: int, world_size: int, device, band_rows: int = BAND_ROWS):
+        self.rank, self.world_size = rank, world_size
+        self.params = band_params(params, rank, world_size, band_rows)
+        self.all_params = [band_params(params, r, world_size, band_rows) for r in range(world_size)]
+        self.max_rows = max(local_rows(p) for p in self.all_params)
+        self.width = params.width
+        self.shard = torch.zeros((self.max_rows, params.width), dtype=torch.int32, device=device)
+        # concatenation of the shards along rows; viewed as [rank, row, x]
+        self._gathered_flat = torch.zeros((world_size * self.max_rows, params.width), dtype=torch.int32, device=device)
+        self.gathered = self._gathered_flat.view(world_size, self.max_rows, params.width)
+
+    def gather(self):
+        if self.world_size > 1:
+            dist.all_gather_into_tensor(self._gathered_flat, self.shard)
+        else:
+            self.gathered[0].copy_(self.shard)
+
+    def assemble(self) -> torch.Tensor:
+        """Full image [rows, W] in global row order (call after gather)."""
+        total = self.all_params[0].row_end - self.all_params[0].row_begin
+        begin = self.all_params[0].row_begin
+        image = torch.zeros((total, self.width), dtype=torch.int32, device=self.gathered.device)
+        for r, p in enumerate(self.all_params):
+            rows = torch.tensor([g - begin for g in global_rows(p)], dtype=torch.long, device=self.gathered.device)
+            if len(rows):
+                image[rows] = self.gathered[r, :len(rows)]
+        return image
+
+
+def reduce_radiance_sum(radiance_sum: torch.Tensor, world_size: int):
+    """Adds every rank's un-normalised radiance sum onto rank 0 (in place)."""
+    if world_size > 1:
+        dist.reduce(radiance_sum, dst=0, op=dist.ReduceOp.SUM)
+
+
+def sum_rays(rays: torch.Tensor, world_size: int) -> torch.Tensor:
+    if world_size > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    return rays
+
+
+def render_rows(render: Callable, params, rank: int, world_size: int, device) -> tuple[RowShardedImage, int]:
+    """rows mode in one call: render this rank's bands, gather.  `render(params, shard) -> rays`."""
+    img = RowShardedImage(params, rank, world_size, device)
+    rays = 0
+    if local_rows(img.params):
+        rays = render(img.params, img.shard)
+    img.gather()
+    return img, rays
+
+
+def render_samples(render: Callable, resolve: Callable, params, rank: int, world_size: int, device,
+                   output_sum_flag: int):
+    """samples mode in one call.  `render(params, radiance_sum) -> rays` fills [H, W, 3] float32;
+    `resolve(radiance_sum, total_spp) -> pixels` runs on rank 0 only.  Returns (pixels or None, rays)."""
+    p = batch_params(params, rank, world_size, output_sum_flag)
+    rows = p.row_end - p.row_begin
+    radiance_sum = torch.zeros((rows, p.width, 3), dtype=torch.float32, device=device)
+    rays = render(p, radiance_sum)
+    reduce_radiance_sum(radiance_sum, world_size)
+    pixels = resolve(radiance_sum, p.samples_per_pixel * world_size) if rank == 0 else None
+    return pixels, rays

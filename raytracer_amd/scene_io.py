@@ -55,6 +55,8 @@ class Scene:
 def read_scene(path) -> Scene:
     with open(path, "rb") as f:
         data = f.read()
+    if len(data) < _HEADER.size:
+        raise ValueError(f"{path}: truncated RTSC header")
     magic, version, nm, npl, ns, nr = _HEADER.unpack_from(data, 0)
     if magic != b"RTSC" or version != 1:
         raise ValueError(f"{path}: not an RTSC v1 scene file")

@@ -1,11 +1,27 @@
-"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs."""
+"""GPU parity: the HIP path, called through the C ABI, against (a) images and ray counts the
+reference renderer itself produced (tests/golden) and (b) the CPU oracle on the same inputs.
+
+Bars.  Linear radiance and ray counts: bit-exact.  Packed 8-bit pixels: at most 1 LSB on at most
+1e-4 of the channels, because the device evaluates the sRGB pow in double precision while glibc's
+powf (what the reference calls) is not correctly rounded.  Sphere normals in WIDE8 mode use the
+correctly rounded 1/sqrt where the reference uses the x86 rsqrt approximation; there the oracle's
+WIDE8_IEEE mode is the bit-exact twin and the reference image is matched statistically.
+"""
+import ctypes as C
+import hashlib
+import json
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
 from raytracer_amd import binding as B
+from raytracer_amd import scene_io
+from raytracer_amd.host_scene import build_scene
 
 pytestmark = pytest.mark.gpu
+
+ORACLE_MODE = {B.INTERSECT_WIDE8: O.WIDE8_IEEE, B.INTERSECT_SCALAR: O.SCALAR}
 
 
 @pytest.fixture(scope="module")
@@ -15,50 +31,261 @@ def ctx():
     c.close()
 
 
-def _oracle_params(p: B.RenderParams, intersect_mode):
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_params(p: B.RenderParams, mode=None):
     return O.default_params(
         p.width, p.height, p.samples_per_pixel, row_begin=p.row_begin, row_end=p.row_end,
         band_rows=p.band_rows, band_index=p.band_index, band_count=p.band_count,
         max_bounces=p.max_bounces, min_hit_distance=p.min_hit_distance, plane_tolerance=p.plane_tolerance,
         seed_constant=p.seed_constant, rng_mode=p.rng_mode, rows_per_order=p.rows_per_order,
-        lanes_per_pixel=p.lanes_per_pixel, batch_offset=p.batch_offset, intersect_mode=intersect_mode,
+        lanes_per_pixel=p.lanes_per_pixel, batch_offset=p.batch_offset,
+        intersect_mode=ORACLE_MODE[p.intersect_mode] if mode is None else mode,
         output_sum=1 if p.flags & B.FLAG_OUTPUT_SUM else 0)
 
 
-def _compare(ctx, scene, p, oracle_mode, exact_pixels=True):
+def channels(pix):
+    return ((pix[..., None] >> np.array([16, 8, 0], dtype=np.uint32)) & 255).astype(int)
+
+
+def assert_pixels_close(pix, ref):
+    diff = np.abs(channels(pix) - channels(ref))
+    assert diff.max() <= 1, f"8-bit difference {diff.max()}"
+    assert (diff != 0).mean() <= 1e-4, f"{(diff != 0).sum()} channels differ by 1 LSB"
+    assert np.array_equal(pix >> 24, ref >> 24)
+
+
+def check_against_oracle(ctx, scene, p, threads=None, oracle_mode=None):
     ctx.upload_world(scene)
     pix, rad, rays = ctx.render(p)
-    opix, orad, orays = O.OracleScene(scene).render(_oracle_params(p, oracle_mode))
+    opix, orad, orays = O.OracleScene(scene).render(oracle_params(p, oracle_mode), threads=threads)
     assert rays == orays
-    # linear radiance: bit-exact
-    assert np.array_equal(rad.view(np.uint32), orad.view(np.uint32)), \
-        f"max abs diff {np.abs(rad - orad).max()} at {(rad != orad).sum()} values"
-    # 8-bit: the device evaluates the sRGB pow in double, glibc's powf is not correctly
-    # rounded: allow 1 LSB at <= 1e-4 of the channels.
-    diff = np.abs(((pix[..., None] >> np.array([16, 8, 0])) & 255).astype(int) -
-                  ((opix[..., None] >> np.array([16, 8, 0])) & 255).astype(int))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
-    assert np.array_equal(pix >> 24, opix >> 24)
-    return rays
+    assert np.array_equal(bits(rad), bits(orad)), \
+        f"radiance differs at {(bits(rad) != bits(orad)).sum()} values, max abs {np.nanmax(np.abs(rad - orad))}"
+    if not p.flags & B.FLAG_OUTPUT_SUM:
+        assert_pixels_close(pix, opix)
+    return pix, rad, rays
 
+
+def psnr8(a, b):
+    mse = np.mean((channels(a) - channels(b)).astype(np.float64) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+# ---------------------------------------------------------------- against the reference's own output
+
+def test_cornell_reproduces_the_reference_image(ctx, cornell, golden_dir):
+    """ROW_SERIAL + WIDE8 on the Cornell box: same random streams, same arithmetic -> the
+    reference's linear radiance and ray count, bit for bit (reference built with -ffp-contract=off)."""
+    g = np.load(golden_dir / "image_cornell_64x36_16spp.npz")
+    ctx.upload_world(cornell)
+    pix, rad, rays = ctx.render(B.default_params(64, 36, 16, rng_mode=B.RNG_ROW_SERIAL))
+    assert rays == int(g["rays"]) == 100810
+    assert np.array_equal(bits(rad), bits(g["radiance"]))
+    assert_pixels_close(pix, g["pixels"])
+
+
+@pytest.mark.parametrize("name", ["cornell", "spheres", "random61", "glass3"])
+def test_single_work_order_images(ctx, golden_dir, name):
+    """One WorkOrder for the whole image (the reference's SINGLE_THREAD shape, main.cpp:418-430)."""
+    g = np.load(golden_dir / f"image_{name}_48x20_8spp_oneorder.npz")
+    scene = scene_io.read_scene(golden_dir / f"{name}.rtsc")
+    ctx.upload_world(scene)
+    p = B.default_params(48, 20, 8, rng_mode=B.RNG_ROW_SERIAL, rows_per_order=0)
+    pix, rad, rays = ctx.render(p)
+    if name == "cornell":
+        assert rays == int(g["rays"]) and np.array_equal(bits(rad), bits(g["radiance"]))
+    else:
+        # spheres: the reference scales normals by the x86 rsqrt approximation (relative error
+        # <= 3.7e-4); paths stay the same until that perturbation flips a decision, after which
+        # the one serial stream of this order is consumed differently.  Statistical agreement:
+        assert abs(rays - int(g["rays"])) <= 0.02 * int(g["rays"])
+        assert abs(rad.mean() - g["radiance"].mean()) <= 0.15 * g["radiance"].mean() + 1e-3
+    check_against_oracle(ctx, scene, p, threads=1)
+
+
+def test_cornell_full_size_known_answer(ctx, cornell, golden_dir):
+    """1280x720 at 512 spp, the size the reference ships: 1.29e9 rays through the ROW_SERIAL kernel
+    must hash to the reference's radiance image (sha256 over the float32 bytes)."""
+    k = json.loads((golden_dir / "known_answers.json").read_text())["cornell_1280x720_512spp_strict"]
+    ctx.upload_world(cornell)
+    pix, rad, rays = ctx.render(B.default_params(1280, 720, 512, rng_mode=B.RNG_ROW_SERIAL))
+    assert rays == k["rays"] == 1293078337
+    assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
+
+
+def test_spheres_full_size_scalar_routine(ctx, spheres, golden_dir):
+    """Spheres + plane at 1280x720x512 (BASELINE configs[0]).  WIDE8 differs from the reference only in
+    the sphere-normal rsqrt, so the image matches statistically; mean radiance within 0.5 %."""
+    k = json.loads((golden_dir / "known_answers.json").read_text())["spheres_1280x720_512spp_strict"]
+    ctx.upload_world(spheres)
+    pix, rad, rays = ctx.render(B.default_params(1280, 720, 512, rng_mode=B.RNG_ROW_SERIAL))
+    assert abs(rays - k["rays"]) <= 1e-3 * k["rays"]
+    mean = rad.reshape(-1, 3).mean(axis=0, dtype=np.float64)
+    assert np.allclose(mean, k["mean_radiance"], rtol=5e-3)
+
+
+# ---------------------------------------------------------------- against the oracle, same inputs
 
 @pytest.mark.parametrize("rng_mode", [B.RNG_ROW_SERIAL, B.RNG_PIXEL])
-def test_cornell_wide_bit_exact(ctx, cornell, rng_mode):
-    p = B.default_params(64, 36, 16, rng_mode=rng_mode)
-    rays = _compare(ctx, cornell, p, O.WIDE8)
-    if rng_mode == B.RNG_ROW_SERIAL:
-        assert rays == 100810  # the reference itself (-ffp-contract=off build) on this input
+@pytest.mark.parametrize("imode", [B.INTERSECT_WIDE8, B.INTERSECT_SCALAR])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "random61", "glass3"])
+def test_scenes_bit_exact(ctx, golden_dir, name, imode, rng_mode):
+    scene = scene_io.read_scene(golden_dir / f"{name}.rtsc")
+    check_against_oracle(ctx, scene, B.default_params(64, 36, 16, rng_mode=rng_mode, intersect_mode=imode))
 
 
-@pytest.mark.parametrize("rng_mode", [B.RNG_ROW_SERIAL, B.RNG_PIXEL])
-@pytest.mark.parametrize("scene_name", ["cornell", "spheres"])
-def test_scalar_bit_exact(ctx, request, scene_name, rng_mode):
-    scene = request.getfixturevalue(scene_name)
-    p = B.default_params(64, 36, 16, rng_mode=rng_mode, intersect_mode=B.INTERSECT_SCALAR)
-    _compare(ctx, scene, p, O.SCALAR)
-
-
-@pytest.mark.parametrize("lanes", [2, 8, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 8, 64])
 def test_pixel_mode_lanes_per_pixel(ctx, cornell, lanes):
-    p = B.default_params(50, 30, 64, rng_mode=B.RNG_PIXEL, lanes_per_pixel=lanes)
-    _compare(ctx, cornell, p, O.WIDE8)
+    check_against_oracle(ctx, cornell, B.default_params(50, 30, 64, rng_mode=B.RNG_PIXEL, lanes_per_pixel=lanes))
+
+
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (7, 3, 5), (65, 9, 2), (129, 17, 3)])
+def test_ragged_sizes(ctx, cornell, w, h, spp):
+    for rng_mode in (B.RNG_ROW_SERIAL, B.RNG_PIXEL):
+        check_against_oracle(ctx, cornell, B.default_params(w, h, spp, rng_mode=rng_mode))
+
+
+def test_row_ranges_and_bands(ctx, cornell):
+    check_against_oracle(ctx, cornell, B.default_params(40, 30, 8, row_begin=7, row_end=19))
+    check_against_oracle(ctx, cornell, B.default_params(40, 30, 8, rng_mode=B.RNG_ROW_SERIAL, row_begin=7, row_end=19,
+                                                        rows_per_order=3))
+    for index in range(3):
+        check_against_oracle(ctx, cornell, B.default_params(40, 30, 8, band_rows=8, band_index=index, band_count=3))
+        check_against_oracle(ctx, cornell, B.default_params(40, 30, 8, rng_mode=B.RNG_ROW_SERIAL, band_rows=4,
+                                                            band_index=index, band_count=3, rows_per_order=2))
+
+
+def test_bands_tile_the_full_render(ctx, cornell):
+    ctx.upload_world(cornell)
+    full_pix, full_rad, full_rays = ctx.render(B.default_params(64, 45, 8))
+    rad = np.zeros_like(full_rad)
+    rays = 0
+    for index in range(4):
+        p = B.default_params(64, 45, 8, band_rows=8, band_index=index, band_count=4)
+        _, r, n = ctx.render(p)
+        rad[B.global_rows(p)] = r
+        rays += n
+    assert rays == full_rays and np.array_equal(bits(rad), bits(full_rad))
+
+
+def test_sample_batches_and_resolve(ctx, spheres):
+    """Two passes with distinct batch offsets, summed, equal the one render with all the batches;
+    rt_resolve_device tonemaps the sum like the fused epilogue."""
+    import torch
+    ctx.upload_world(spheres)
+    whole_pix, whole, rays = ctx.render(B.default_params(48, 32, 32, lanes_per_pixel=8))
+    dev = torch.device("cuda", 0)
+    acc = torch.zeros((32, 48, 3), dtype=torch.float32, device=dev)
+    part = torch.zeros_like(acc)
+    nrays = torch.zeros(2, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for i, off in enumerate((0, 4)):
+        p = B.default_params(48, 32, 16, lanes_per_pixel=4, batch_offset=off, flags=B.FLAG_OUTPUT_SUM)
+        ctx.render_device(p, None, part.data_ptr(), nrays.data_ptr() + 8 * i, stream.cuda_stream)
+        acc += part
+    pixels = torch.zeros((32, 48), dtype=torch.int32, device=dev)
+    mean = torch.zeros_like(acc)
+    ctx.resolve_device(acc.data_ptr(), 32 * 48, 32, pixels.data_ptr(), mean.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert int(nrays.sum()) == rays
+    assert np.array_equal(bits(mean.cpu().numpy()), bits(whole))
+    assert np.array_equal(pixels.cpu().numpy().view(np.uint32), whole_pix)
+
+
+@pytest.mark.parametrize("bounces", [1, 3, 32])
+def test_bounce_cap(ctx, golden_dir, bounces):
+    scene = scene_io.read_scene(golden_dir / "glass3.rtsc")
+    check_against_oracle(ctx, scene, B.default_params(48, 27, 16, max_bounces=bounces))
+    check_against_oracle(ctx, scene, B.default_params(48, 27, 4, max_bounces=bounces, rng_mode=B.RNG_ROW_SERIAL))
+
+
+def test_seed_constant_and_tolerances(ctx, spheres):
+    a = check_against_oracle(ctx, spheres, B.default_params(32, 18, 8, seed_constant=777767))
+    b = check_against_oracle(ctx, spheres, B.default_params(32, 18, 8))
+    assert not np.array_equal(a[1], b[1])
+    check_against_oracle(ctx, spheres, B.default_params(32, 18, 8, min_hit_distance=0.01, plane_tolerance=0.05))
+
+
+def test_mixed_scene_spheres_and_rectangles(ctx, cornell, spheres):
+    """Spheres inside the Cornell box: exercises the kernel variant that orders sphere/rectangle ties."""
+    sp = spheres.spheres.copy()
+    sp["position"] = sp["position"] * np.float32(0.8) + np.array([0, -7, -7], dtype=np.float32)
+    sp["material_index"] = np.array([1, 2, 3, 1, 2, 3, 4, 1], dtype=np.uint32)
+    scene = scene_io.Scene(cornell.materials, np.zeros(0, dtype=scene_io.PLANE), sp, cornell.rectangles, cornell.camera)
+    for imode in (B.INTERSECT_WIDE8, B.INTERSECT_SCALAR):
+        for rng_mode in (B.RNG_ROW_SERIAL, B.RNG_PIXEL):
+            check_against_oracle(ctx, scene, B.default_params(64, 36, 16, intersect_mode=imode, rng_mode=rng_mode))
+
+
+def test_odd_rectangle_count_is_padded(ctx, cornell):
+    scene = scene_io.Scene(cornell.materials, cornell.planes, cornell.spheres, cornell.rectangles[:17], cornell.camera)
+    check_against_oracle(ctx, scene, B.default_params(64, 36, 8))
+
+
+def test_stress_scenes_reduced_size(ctx):
+    """The LDS-stress (4096 spheres) and divergence-stress (glass, 32 bounces) scenes at a size the oracle renders in seconds."""
+    check_against_oracle(ctx, build_scene("random_spheres", 4096, 1), B.default_params(64, 36, 4))
+    check_against_oracle(ctx, build_scene("glass_spheres", 5), B.default_params(64, 36, 16, max_bounces=32))
+
+
+def test_bench_size_cornell_bit_exact(ctx, cornell):
+    """The benchmarked workload itself - Cornell 1920x1080 at 256 spp, PIXEL mode, 1.45e9 rays - is
+    bit-identical to the CPU oracle."""
+    check_against_oracle(ctx, cornell, B.default_params(1920, 1080, 256), oracle_mode=O.WIDE8_AVX2)
+
+
+def test_image_statistics_match_the_reference(ctx, cornell, golden_dir):
+    """PIXEL-mode streams differ from the reference's row streams, so agreement is statistical: image
+    mean within 1 % of the reference's 320x180x64 render (two reference seeds differ by more)."""
+    k = json.loads((golden_dir / "known_answers.json").read_text())["cornell_320x180_64spp_strict"]
+    ctx.upload_world(cornell)
+    _, rad, rays = ctx.render(B.default_params(320, 180, 64))
+    mean = rad.reshape(-1, 3).mean(axis=0, dtype=np.float64)
+    assert np.allclose(mean, k["mean_radiance"], rtol=1e-2)
+    assert abs(rays - k["rays"]) <= 5e-3 * k["rays"]
+
+
+def test_runs_are_deterministic(ctx, cornell):
+    ctx.upload_world(cornell)
+    a = ctx.render(B.default_params(200, 120, 32))
+    b = ctx.render(B.default_params(200, 120, 32))
+    assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+# ---------------------------------------------------------------- error behaviour
+
+def test_errors(ctx, cornell):
+    fresh = B.Context(0)
+    with pytest.raises(B.RtError) as e:
+        fresh.render(B.default_params(8, 8, 1))
+    assert e.value.status == 4                                  # RT_ERR_NO_WORLD
+    fresh.close()
+    ctx.upload_world(cornell)
+    bad = [dict(samples_per_pixel=0), dict(width=0), dict(row_begin=5, row_end=5), dict(row_end=99),
+           dict(lanes_per_pixel=3), dict(lanes_per_pixel=128), dict(samples_per_pixel=6, lanes_per_pixel=4),
+           dict(max_bounces=0), dict(rng_mode=7), dict(intersect_mode=9), dict(struct_size=12),
+           dict(band_rows=8, band_index=3, band_count=3)]
+    for fields in bad:
+        with pytest.raises(B.RtError) as e:
+            ctx.render(B.default_params(16, 16, 4, **fields))
+        assert e.value.status == 1, fields                      # RT_ERR_INVALID_ARGUMENT
+    big = build_scene("random_spheres", 20000, 1)               # 400 KB of spheres: more than one workgroup's LDS
+    with pytest.raises(B.RtError) as e:
+        ctx.upload_world(big)
+    assert e.value.status == 5                                  # RT_ERR_TOO_LARGE
+    ctx.upload_world(cornell)                                   # the context is still usable
+    ctx.render(B.default_params(16, 16, 4))
+
+
+def test_kernel_timer(ctx, cornell):
+    ctx.upload_world(cornell)
+    import torch
+    dev = torch.device("cuda", 0)
+    pix = torch.zeros((90, 160), dtype=torch.int32, device=dev)
+    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctx.render_device(B.default_params(160, 90, 64, flags=B.FLAG_TIME_KERNEL), pix.data_ptr(), None, rays.data_ptr(), None)
+    ms = ctx.last_kernel_ms()
+    assert 0 < ms < 1000 and int(rays.item()) > 160 * 90 * 64
