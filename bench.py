@@ -77,6 +77,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import binding as B
+    from raytracer_amd import distributed as D
     from raytracer_amd.host_scene import build_scene
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,25 +103,21 @@ def main():
     ctx.upload_world(build_scene("cornell"))
 
     rows_mode = distributed and args.shard == "rows"
-    p = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes)
-    if rows_mode:
-        p.band_rows, p.band_index, p.band_count = 8, rank, world_size
-    elif distributed:
-        p.batch_offset = rank * B_lanes
-        p.flags = B.FLAG_OUTPUT_SUM
-    local_rows = B.local_row_count(p)
-
+    base = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes)
     total = args.steps + args.warmup
-    pixels = torch.zeros((local_rows, W), dtype=torch.int32, device=device)
     rays = torch.zeros(total, dtype=torch.int64, device=device)
-    radiance = torch.zeros((H, W, 3), dtype=torch.float32, device=device) if (distributed and not rows_mode) else None
-    gathered = None
+    radiance = None
+    sharded = None
     if rows_mode:
-        # all ranks need equal-sized shards for all_gather: pad to the largest shard
-        max_rows = max(B.local_row_count(B.default_params(W, H, spp, band_rows=8, band_index=r, band_count=world_size))
-                       for r in range(world_size))
-        pixels = torch.zeros((max_rows, W), dtype=torch.int32, device=device)
-        gathered = torch.zeros((world_size, max_rows, W), dtype=torch.int32, device=device)
+        sharded = D.RowShardedImage(base, rank, world_size, device)     # interleaved 8-row bands + all_gather buffers
+        p, pixels = sharded.params, sharded.shard
+    elif distributed:
+        p = D.batch_params(base, rank, world_size, B.FLAG_OUTPUT_SUM)   # this rank's sample batches, un-normalised sum
+        radiance = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+        pixels = torch.zeros((H, W), dtype=torch.int32, device=device)
+    else:
+        p = base
+        pixels = torch.zeros((H, W), dtype=torch.int32, device=device)
 
     stream = torch.cuda.current_stream(device)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
@@ -135,9 +132,9 @@ def main():
             ctx.render_device(p, pixels.data_ptr(), None, d_rays, stream.cuda_stream)
         stops[i].record(stream)
         if rows_mode:
-            dist.all_gather_into_tensor(gathered, pixels)
+            sharded.gather()
         elif distributed:
-            dist.reduce(radiance, dst=0, op=dist.ReduceOp.SUM)
+            D.reduce_radiance_sum(radiance, world_size)
             if rank == 0:
                 ctx.resolve_device(radiance.data_ptr(), W * H, spp * world_size, pixels.data_ptr(), None, stream.cuda_stream)
 

@@ -79,6 +79,13 @@ def load_library() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch wheels bundle their own ROCm runtime.  A process that uses both must load torch's
+    # copy first, so that librt_hip.so binds to the same libamdhip64 instead of bringing up a
+    # second HIP runtime (after which torch finds no GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     L.rt_abi_version.restype = C.c_uint32
     L.rt_status_string.restype = C.c_char_p

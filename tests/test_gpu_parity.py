@@ -269,8 +269,11 @@ def test_errors(ctx, cornell):
            dict(max_bounces=0), dict(rng_mode=7), dict(intersect_mode=9), dict(struct_size=12),
            dict(band_rows=8, band_index=3, band_count=3)]
     for fields in bad:
+        p = B.default_params(16, 16, 4)
+        for k, v in fields.items():
+            setattr(p, k, v)
         with pytest.raises(B.RtError) as e:
-            ctx.render(B.default_params(16, 16, 4, **fields))
+            ctx.render(p)
         assert e.value.status == 1, fields                      # RT_ERR_INVALID_ARGUMENT
     big = build_scene("random_spheres", 20000, 1)               # 400 KB of spheres: more than one workgroup's LDS
     with pytest.raises(B.RtError) as e:
