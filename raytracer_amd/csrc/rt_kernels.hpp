@@ -101,7 +101,9 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t& s) {
     return x;
 }
 __device__ __forceinline__ float random_unilateral(uint32_t& s) { return (float)xorshift32(s) * 0x1.0p-32f; }
-__device__ __forceinline__ float random_bilateral(uint32_t& s) { return 2.0f * random_unilateral(s) - 1.0f; }
+// 2u - 1: u = x * 2^-32 and 2u are exact scalings, so the one rounding of fma(x, 2^-31, -1) is
+// the one rounding of the reference's subtraction.
+__device__ __forceinline__ float random_bilateral(uint32_t& s) { return __builtin_fmaf((float)xorshift32(s), 0x1.0p-31f, -1.0f); }
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu;
@@ -154,11 +156,12 @@ struct SceneView {
 
 // World intersection.  best_id: 0 = miss, 1+i plane i, 1+np+k sphere slot k,
 // 1+np+ns+k rectangle slot k (slots in the image's order).
+struct Closest { float t; uint32_t id; };
+
 template <int IMODE, bool MIXED>
-__device__ __forceinline__ void intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
-                                                float& best_t, uint32_t& best_id) {
-    best_t = 3.402823466e+38f;  // F32Max
-    best_id = 0;
+__device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol) {
+    float best_t = 3.402823466e+38f;  // F32Max
+    uint32_t best_id = 0;
     uint32_t best_lane = 0;     // WIDE8 + MIXED: AVX lane of the best hit when it is a sphere
 
     // Planes: scalar code in both reference routines (main.cpp:37-50, 168-180).
@@ -254,6 +257,10 @@ __device__ __forceinline__ void intersect_world(const SceneView& sv, V3 o, V3 d,
             }
         }
     }
+    Closest c;
+    c.t = best_t;
+    c.id = best_id;
+    return c;
 }
 
 struct Hit { V3 normal; uint32_t material; };
@@ -399,16 +406,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, c
 
     V3 pixel_sum = mk(0.0f, 0.0f, 0.0f);
     V3 ro = cam_pos, rd = mk(0.0f, 0.0f, 1.0f), attenuation = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+    V3 next_dir = mk(0.0f, 0.0f, 1.0f);   // direction of the lane's next ray, before normalisation
     uint32_t bounce = 0;
-    bool in_path = false;
+    bool in_path = false;                 // the lane has a ray to intersect in this iteration
+    bool need_sample = has_pixel;         // the lane's previous path ended (or it has not started one)
     unsigned long long ray_count = 0;
     uint32_t pixel_rays = 0;
 
     while (true) {
-        // ---- start the next sample of this lane's list (main.cpp:381-388) ----------
-        if (!in_path && has_pixel) {
+        // ---- lanes between paths: close the pixel if it is complete, start the next sample
+        //      (main.cpp:379-388).  Only the un-normalised primary direction is formed here; the
+        //      normalisation below is shared with the lanes that continue a path.
+        if (need_sample) {
+            need_sample = false;
             if (samples_left == 0) {
-                // every sample of the pixel has finished
                 if (RMODE == RT_RNG_ROW_SERIAL) {
                     emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
                     ray_count += pixel_rays;
@@ -436,29 +447,28 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, c
                 float off_y = film_y + random_bilateral(state) * p.pixel_h;
                 V3 film_pos = film_center + cam_x * off_x * p.half_w + cam_y * p.half_h * off_y;
                 ro = cam_pos;
-                rd = normalize(film_pos - cam_pos);
+                next_dir = film_pos - cam_pos;
                 attenuation = mk(1.0f, 1.0f, 1.0f);
                 result = mk(0.0f, 0.0f, 0.0f);
                 bounce = 0;
                 in_path = true;
             }
         }
-        if (__ballot(in_path) == 0ull) break;   // no lane of the wave has a path to extend
+        if (__ballot(in_path) == 0ull) break;   // no lane of the wave has a ray left
 
-        // ---- one bounce (main.cpp:275-330) -------------------------------------------
+        // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
         if (in_path) {
-            float t;
-            uint32_t best_id;
-            intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol, t, best_id);
+            rd = normalize(next_dir);
+            const Closest c = intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol);
             ++pixel_rays;
             ++bounce;
-            if (best_id != 0) {
-                Hit h = resolve_hit<IMODE>(sv, best_id, t, ro, rd);
+            if (c.id != 0) {
+                Hit h = resolve_hit<IMODE>(sv, c.id, c.t, ro, rd);
                 const float4* m = reinterpret_cast<const float4*>(sv.f + sv.off_mats + MAT_WORDS * h.material);
                 const float4 m0 = m[0], m1 = m[1], m2 = m[2];   // color ri | emit reflection | 1/ri r0
                 result = result + attenuation * mk(m1.x, m1.y, m1.z);
                 attenuation = attenuation * mk(m0.x, m0.y, m0.z);
-                ro = ro + rd * t;
+                ro = ro + rd * c.t;
 
                 V3 n = h.normal;
                 V3 mirror = rd - n * dot(n, rd) * 2.0f;
@@ -468,24 +478,25 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, c
                 float rx = random_bilateral(state);
                 V3 random_bounce = n + mk(rx, ry, rz);
                 float refl = m1.w;
-                V3 reflected = normalize(random_bounce * (1.0f - refl) + mirror * refl);   // Lerp, math_util.h:24-26
-
+                // The reference normalises the reflected and the refracted candidate and then picks
+                // one (main.cpp:295-322); picking first and normalising once gives the same vector.
+                V3 reflected = random_bounce * (1.0f - refl) + mirror * refl;   // Lerp, math_util.h:24-26
                 float fresnel = 1.0f;
                 V3 refracted = reflected;
                 if (m0.w != 0.0f) {
-                    if (refract(rd, n, m0.w, m2.x, refracted)) {
-                        refracted = normalize(refracted);
-                        fresnel = schlick(rd, n, m2.y);
-                    }
+                    if (refract(rd, n, m0.w, m2.x, refracted)) fresnel = schlick(rd, n, m2.y);
                 }
-                rd = (random_unilateral(state) <= fresnel) ? reflected : refracted;
+                next_dir = (random_unilateral(state) <= fresnel) ? reflected : refracted;
                 if (bounce >= p.max_bounces) in_path = false;
             } else {
                 const float4 sky = *reinterpret_cast<const float4*>(sv.f + sv.off_mats + 4);   // materials[0].emit
                 result = result + attenuation * mk(sky.x, sky.y, sky.z);
                 in_path = false;
             }
-            if (!in_path) pixel_sum = pixel_sum + result;   // color += RaytraceWorld(...) (main.cpp:390)
+            if (!in_path) {
+                pixel_sum = pixel_sum + result;   // color += RaytraceWorld(...) (main.cpp:390)
+                need_sample = true;
+            }
         }
     }
 
