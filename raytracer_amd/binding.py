@@ -12,8 +12,11 @@ import numpy as np
 
 from .scene_io import Scene
 
+import os
+
 _PKG = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG / "librt_hip.so"
+# RT_HIP_LIBRARY selects another build of the same library (A/B runs of kernel variants).
+LIB_PATH = pathlib.Path(os.environ.get("RT_HIP_LIBRARY", _PKG / "librt_hip.so"))
 
 RT_OK = 0
 RNG_ROW_SERIAL, RNG_PIXEL = 0, 1

@@ -344,7 +344,10 @@ __device__ __forceinline__ void emit_pixel(const KernelParams& p, V3 sum, size_t
     }
 }
 
-constexpr int BLOCK_THREADS = 256;
+#ifndef RT_BLOCK_THREADS
+#define RT_BLOCK_THREADS 256
+#endif
+constexpr int BLOCK_THREADS = RT_BLOCK_THREADS;
 
 template <int IMODE, int RMODE, bool MIXED>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
