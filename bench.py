@@ -2,8 +2,8 @@
 """Benchmark of the HIP path-tracing hot path: Mrays/s on the Cornell box at 1920x1080.
 
 A step is one render of the whole image on every rank (scene already resident in
-HBM, outputs left in HBM).  N = 1: Cornell 1920x1080 at 256 spp (BASELINE.json
-configs[1]).  N > 1, default --shard samples (weak scaling): every rank renders all
+HBM, outputs left in HBM).  N = 1: Cornell 1920x1080 at 256 spp (the headline
+single-GPU configuration).  N > 1, default --shard samples (weak scaling): every rank renders all
 pixels at 256 spp with its own sample-batch indices, so the job is 1080p at 256*N
 spp; the per-rank radiance sums are added onto rank 0 with one RCCL reduce and
 rank 0 tonemaps.  --shard rows (strong scaling) splits the 256-spp image into
@@ -182,7 +182,7 @@ def main():
         elif distributed:
             workload = f"Cornell box {W}x{H} {spp * world_size} spp, {spp} spp per GPU (sample batches), RCCL reduce"
         else:
-            workload = f"Cornell box {W}x{H} {spp} spp (BASELINE.json configs[1])"
+            workload = f"Cornell box {W}x{H} {spp} spp on one GPU"
         line = {
             "metric": "Mrays/s (whole node) Cornell box 1080p",
             "value": round(mrays, 1),

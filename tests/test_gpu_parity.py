@@ -117,7 +117,7 @@ def test_cornell_full_size_known_answer(ctx, cornell, golden_dir):
 
 
 def test_spheres_full_size_scalar_routine(ctx, spheres, golden_dir):
-    """Spheres + plane at 1280x720x512 (BASELINE configs[0]).  WIDE8 differs from the reference only in
+    """Spheres + plane at 1280x720x512 (the reference's spheres scene at the size it ships).  WIDE8 differs from the reference only in
     the sphere-normal rsqrt, so the image matches statistically; mean radiance within 0.5 %."""
     k = json.loads((golden_dir / "known_answers.json").read_text())["spheres_1280x720_512spp_strict"]
     ctx.upload_world(spheres)
