@@ -292,3 +292,21 @@ def test_kernel_timer(ctx, cornell):
     ctx.render_device(B.default_params(160, 90, 64, flags=B.FLAG_TIME_KERNEL), pix.data_ptr(), None, rays.data_ptr(), None)
     ms = ctx.last_kernel_ms()
     assert 0 < ms < 1000 and int(rays.item()) > 160 * 90 * 64
+
+
+def test_packed_division_is_ieee_division():
+    """rt::div2 (reciprocal + packed refinement, no operand scaling) against the compiler's IEEE
+    division on 2.1e9 random quotients: mantissas uniform, exponents spanning 2^-40 .. 2^40 (the
+    rectangle test's operands are distances and direction components of order 1e-7 .. 1e3)."""
+    import pathlib
+    lib = C.CDLL(str(pathlib.Path(B.LIB_PATH).with_name("librt_selftest.so")))
+    lib.rt_selftest_div2.restype = C.c_int
+    lib.rt_selftest_div2.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    bad, tested = C.c_uint64(0), C.c_uint64(0)
+    first = np.zeros(4, dtype=np.float32)
+    rc = lib.rt_selftest_div2(12345, 4096, 1024, 127 - 40, 127 + 40, C.byref(bad), C.byref(tested),
+                              first.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert tested.value == 4096 * 256 * 1024 * 2
+    assert bad.value == 0, f"{bad.value} of {tested.value} quotients differ, e.g. a, b, div2, ieee = {first}"
