@@ -62,7 +62,7 @@ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 struct Launch {
     rt::KernelParams kp;
-    uint32_t blocks;
+    uint32_t blocks, block_threads;
     int imode, rmode;
 };
 
@@ -86,6 +86,8 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %u", p->rng_mode);
     if (p->intersect_mode != RT_INTERSECT_WIDE8 && p->intersect_mode != RT_INTERSECT_SCALAR)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown intersect_mode %u", p->intersect_mode);
+    if (!(p->min_hit_distance >= 0.0f) || !(p->plane_tolerance >= 0.0f))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "min_hit_distance and plane_tolerance must be >= 0");
     if (p->seed_constant == 0 && p->rng_mode == RT_RNG_ROW_SERIAL)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "seed_constant 0 gives the all-zero xorshift state");
 
@@ -132,7 +134,11 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         k.rows_per_order = 1; k.order_count = 0;
         lanes = (uint64_t)k.tiles_x * k.tiles_y * 64;
     }
-    uint64_t blocks = (lanes + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS;
+    // A CU has 160 KB of LDS and room for 2048 threads: pick the workgroup size so that the LDS
+    // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
+    const size_t image_bytes = (size_t)k.scene_words * 4;
+    out->block_threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
+    uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
     out->blocks = (uint32_t)blocks;
 
@@ -161,7 +167,7 @@ hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(L.blocks), dim3(rt::BLOCK_THREADS), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
+    hipLaunchKernelGGL(kernel, dim3(L.blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
                        d_rays);
     return hipGetLastError();
 }

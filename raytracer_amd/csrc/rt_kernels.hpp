@@ -179,23 +179,38 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     if (sv.n_spheres) {
         const float a = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(d, d) : dot(d, d);
         const float denom = 2.0f * a;
+        const float four_a = 4.0f * a;
+        // Both roots are divided by the same 2a: the reciprocal estimate and its Newton step (the
+        // first three operations of the IEEE division refinement, see div2) are done once per ray.
+        float recip = __builtin_amdgcn_rcpf(denom);
+        recip = __builtin_fmaf(__builtin_fmaf(-denom, recip, 1.0f), recip, recip);
+        const F2 denom2 = splat(denom), recip2 = splat(recip);
         for (uint32_t k = 0; k < sv.n_spheres; ++k) {
             const float4 sp = *reinterpret_cast<const float4*>(sv.f + sv.off_spheres + SPHERE_WORDS * k);
             V3 cto = o - mk(sp.x, sp.y, sp.z);
-            float disc, b;
+            float disc, b, c;
             if (IMODE == RT_INTERSECT_WIDE8) {
                 b = 2.0f * dot_fma(d, cto);
-                float c = dot_fma(cto, cto) - sp.w;
-                disc = __builtin_fmaf(b, b, -(4.0f * a * c));      // FMulSub(b, b, 4ac)
+                c = dot_fma(cto, cto) - sp.w;
+                disc = __builtin_fmaf(b, b, -(four_a * c));        // FMulSub(b, b, 4ac)
             } else {
                 b = 2 * dot(d, cto);
-                float c = dot(cto, cto) - sp.w;
-                disc = b * b - 4 * a * c;
+                c = dot(cto, cto) - sp.w;
+                disc = b * b - four_a * c;
             }
-            if (disc > 0.0f) {
-                float root = __builtin_sqrtf(disc);
-                float tp = (-b + root) / denom;
-                float tn = (-b - root) / denom;
+            // disc > 0: the ray's line meets the sphere.  With b > 0 and c > 0 (centre behind the
+            // origin, origin outside) 4ac > 0, so sqrt(disc) <= sqrt(b*b) = b and both roots are <= 0:
+            // the reference computes them and rejects them against min_hit >= 0; skip them unevaluated.
+            if (disc > 0.0f && !(b > 0.0f && c > 0.0f)) {
+                const float root = __builtin_sqrtf(disc);
+                // (tp, tn) = ((-b + root) / 2a, (-b - root) / 2a), correctly rounded (see div2)
+                const F2 num = f2(-b + root, -b - root);
+                F2 q = num * recip2;
+                F2 r = fma2(-denom2, q, num);
+                q = fma2(r, recip2, q);
+                r = fma2(-denom2, q, num);
+                q = fma2(r, recip2, q);
+                const float tp = q.x, tn = q.y;
                 float t = tp;
                 if (tn > min_hit && tn < tp) t = tn;
                 if (t > min_hit && t < best_t) {
@@ -344,18 +359,18 @@ __device__ __forceinline__ void emit_pixel(const KernelParams& p, V3 sum, size_t
     }
 }
 
-#ifndef RT_BLOCK_THREADS
-#define RT_BLOCK_THREADS 256
-#endif
-constexpr int BLOCK_THREADS = RT_BLOCK_THREADS;
+// Workgroup size is chosen per launch: 256 threads when the scene image is small, up to 1024
+// when it is large, so that one LDS copy of the scene still serves 4 waves per SIMD.
+constexpr int MAX_BLOCK_THREADS = 1024;
+constexpr int BLOCK_THREADS = 256;   // resolve_kernel
 
 template <int IMODE, int RMODE, bool MIXED>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
+__global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
                                                                uint32_t* __restrict__ pixels,
                                                                float* __restrict__ radiance,
                                                                unsigned long long* __restrict__ rays) {
     extern __shared__ uint4 lds_image[];
-    for (uint32_t i = threadIdx.x; i < p.scene_words / 4; i += BLOCK_THREADS) lds_image[i] = scene_image[i];
+    for (uint32_t i = threadIdx.x; i < p.scene_words / 4; i += blockDim.x) lds_image[i] = scene_image[i];
     __syncthreads();
 
     SceneView sv;
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(KernelParams p, c
     const V3 cam_pos = load3(p.cam_pos), cam_x = load3(p.cam_x), cam_y = load3(p.cam_y);
     const V3 film_center = load3(p.film_center);
 
-    const uint32_t gid = blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 
     // ---- this lane's stream and its list of samples --------------------------------
     uint32_t state = 1;
