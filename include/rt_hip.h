@@ -139,7 +139,7 @@ typedef struct rt_device_info {
     uint32_t clock_khz;                /* peak engine clock */
     uint32_t lds_bytes_per_workgroup;  /* opt-in maximum */
     uint64_t global_memory_bytes;
-    double   fp32_vector_peak_tflops;  /* compute_units * 128 lanes * 2 flop * clock (packed-FP32 issue) */
+    double   fp32_vector_peak_tflops;  /* compute_units * 4 SIMDs * 32 FMA lanes * 2 flop * clock */
 } rt_device_info;
 
 typedef struct rt_context rt_context;
@@ -179,6 +179,15 @@ rt_status rt_render(rt_context* context, const rt_render_params* params,
 rt_status rt_render_device(rt_context* context, const rt_render_params* params,
                            uint32_t* d_pixels, float* d_radiance, uint64_t* d_rays,
                            void* hip_stream);
+
+/* Multi-GPU render into HOST memory: the rows [row_begin,row_end) of `params` are cut into bands of
+ * 8 rows, context i renders bands i, i + n, ... concurrently (one host thread per context, the
+ * replacement of the reference's worker threads, main.cpp:450-461, at GPU granularity) and the
+ * bands are interleaved back into full-size outputs: (row_end-row_begin) x width pixels / radiance,
+ * *rays = sum over GPUs.  Every context must hold the same world.  params->band_* are ignored.
+ * The same context may appear more than once (its shares are then rendered one after another). */
+rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
+                          uint32_t* pixels, float* radiance, uint64_t* rays);
 
 /* Tonemap + pack of an accumulated radiance sum (sum over passes or GPUs of
  * RT_FLAG_OUTPUT_SUM renders): pixels[i] = pack(sum[i] / total_samples), the

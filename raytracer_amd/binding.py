@@ -27,7 +27,7 @@ FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL = 1, 2
 EXPORTS = (
     "rt_abi_version", "rt_status_string", "rt_create", "rt_destroy", "rt_error_string",
     "rt_get_device_info", "rt_default_params", "rt_local_row_count", "rt_global_row",
-    "rt_upload_world", "rt_render", "rt_render_device", "rt_resolve_device", "rt_last_kernel_ms",
+    "rt_upload_world", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_last_kernel_ms",
 )
 
 
@@ -113,6 +113,9 @@ def load_library() -> C.CDLL:
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.rt_render_device.restype = C.c_int
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_render_multi.restype = C.c_int
+    L.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_uint64)]
     L.rt_resolve_device.restype = C.c_int
     L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_last_kernel_ms.restype = C.c_int
@@ -144,6 +147,20 @@ def global_rows(params: RenderParams) -> np.ndarray:
 
 def _ptr(arr):
     return arr.ctypes.data_as(C.c_void_p) if arr is not None and arr.size else None
+
+
+def render_multi(contexts, params: RenderParams, want_pixels=True, want_radiance=True):
+    """rt_render_multi over a list of Context objects: full-size host outputs (pixels, radiance, rays)."""
+    L = load_library()
+    rows = params.row_end - params.row_begin
+    pixels = np.zeros((rows, params.width), dtype=np.uint32) if want_pixels else None
+    radiance = np.zeros((rows, params.width, 3), dtype=np.float32) if want_radiance else None
+    rays = C.c_uint64(0)
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    st = L.rt_render_multi(handles, len(contexts), C.byref(params), _ptr(pixels), _ptr(radiance), C.byref(rays))
+    if st != RT_OK:
+        raise RtError(st, L.rt_error_string(contexts[0]._h).decode() or L.rt_status_string(st).decode())
+    return pixels, radiance, int(rays.value)
 
 
 class Context:

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -253,7 +255,7 @@ rt_status rt_get_device_info(const rt_context* ctx, rt_device_info* info) {
     info->lds_bytes_per_workgroup = (uint32_t)ctx->props.sharedMemPerBlockOptin;
     if (info->lds_bytes_per_workgroup == 0) info->lds_bytes_per_workgroup = (uint32_t)ctx->props.sharedMemPerBlock;
     info->global_memory_bytes = ctx->props.totalGlobalMem;
-    // 4 SIMDs x 32 lanes per CU, one FMA (2 flop) per lane per clock when packed-FP32 issue is sustained.
+    // 4 SIMDs x 32 lanes per CU, one FMA (2 flop) per lane per clock.
     info->fp32_vector_peak_tflops = (double)info->compute_units * 128.0 * 2.0 * (double)info->clock_khz * 1.0e3 / 1.0e12;
     return RT_OK;
 }
@@ -376,6 +378,64 @@ rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* p
         RT_HIP_CHECK(ctx, hipMemcpy(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost));
         *rays = r;
     }
+    return RT_OK;
+}
+
+rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
+                          uint32_t* pixels, float* radiance, uint64_t* rays) {
+    if (!contexts || context_count == 0 || !params) return RT_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < context_count; ++i)
+        if (!contexts[i]) return RT_ERR_INVALID_ARGUMENT;
+    if (params->struct_size != sizeof(rt_render_params) || params->row_end <= params->row_begin || params->width == 0)
+        return fail(contexts[0], RT_ERR_INVALID_ARGUMENT, "rt_render_multi: bad struct_size, width or row range");
+    const uint32_t width = params->width;
+    std::vector<rt_render_params> shard_params(context_count, *params);
+    std::vector<std::vector<uint32_t>> shard_pixels(context_count);
+    std::vector<std::vector<float>> shard_radiance(context_count);
+    std::vector<uint64_t> shard_rays(context_count, 0);
+    std::vector<rt_status> status(context_count, RT_OK);
+    for (uint32_t i = 0; i < context_count; ++i) {
+        rt_render_params& p = shard_params[i];
+        p.band_rows = context_count > 1 ? 8u : 0u;
+        p.band_index = i;
+        p.band_count = context_count;
+        size_t count = (size_t)rt_local_row_count(&p) * width;
+        if (pixels) shard_pixels[i].resize(count);
+        if (radiance) shard_radiance[i].resize(count * 3);
+    }
+    // One thread per distinct context; a context listed twice renders its shares back to back.
+    std::vector<std::thread> workers;
+    for (uint32_t i = 0; i < context_count; ++i) {
+        bool first = true;
+        for (uint32_t j = 0; j < i; ++j) first = first && contexts[j] != contexts[i];
+        if (!first) continue;
+        workers.emplace_back([&, i] {
+            for (uint32_t j = i; j < context_count; ++j) {
+                if (contexts[j] != contexts[i]) continue;
+                if (rt_local_row_count(&shard_params[j]) == 0) continue;   // more GPUs than bands
+                status[j] = rt_render(contexts[j], &shard_params[j], pixels ? shard_pixels[j].data() : nullptr,
+                                      radiance ? shard_radiance[j].data() : nullptr, &shard_rays[j]);
+            }
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < context_count; ++i) {
+        if (status[i] != RT_OK) {
+            if (contexts[i] != contexts[0]) contexts[0]->error = contexts[i]->error;
+            return status[i];
+        }
+        total += shard_rays[i];
+        const rt_render_params& p = shard_params[i];
+        const uint32_t rows = rt_local_row_count(&p);
+        for (uint32_t local = 0; local < rows; ++local) {
+            const size_t dst = (size_t)(rt_global_row(&p, local) - params->row_begin) * width;
+            if (pixels) std::memcpy(pixels + dst, shard_pixels[i].data() + (size_t)local * width, (size_t)width * sizeof(uint32_t));
+            if (radiance)
+                std::memcpy(radiance + dst * 3, shard_radiance[i].data() + (size_t)local * width * 3, (size_t)width * 3 * sizeof(float));
+        }
+    }
+    if (rays) *rays = total;
     return RT_OK;
 }
 

@@ -8,7 +8,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -31,6 +30,7 @@ struct Options {
     unsigned count = 0;
     unsigned long long scene_seed = 1;
     int gpus = 1;
+    std::string devices;                     // explicit device ordinals, e.g. "0,1,2,3" (overrides --gpus)
     std::string out = "render.bmp";
 };
 
@@ -39,7 +39,7 @@ void Usage() {
                  "usage: raytracer [--scene cornell|spheres|random_spheres|glass_spheres|FILE.rtsc] [--count N] [--scene-seed S]\n"
                  "                 [--width W] [--height H] [--spp N] [--bounces N] [--seed-constant N]\n"
                  "                 [--rng pixel|row] [--lanes-per-pixel N] [--intersect wide|scalar]\n"
-                 "                 [--gpus N] [--out FILE.bmp]\n");
+                 "                 [--gpus N | --devices 0,1,...] [--out FILE.bmp]\n");
 }
 
 bool Parse(int argc, char** argv, Options* o) {
@@ -61,6 +61,7 @@ bool Parse(int argc, char** argv, Options* o) {
         else if (a == "--lanes-per-pixel") o->lanes_per_pixel = (unsigned)std::strtoul(v, nullptr, 0);
         else if (a == "--intersect") o->intersect = v;
         else if (a == "--gpus") o->gpus = std::atoi(v);
+        else if (a == "--devices") o->devices = v;
         else if (a == "--out") o->out = v;
         else return false;
     }
@@ -86,52 +87,41 @@ int main(int argc, char** argv) {
     if (!world || !image.pixelData) { std::fprintf(stderr, "cannot build scene '%s'\n", opt.scene.c_str()); return 1; }
     rt_world view = world->View();
 
-    // One context per GPU; each renders an interleaved set of 8-row bands straight
-    // into its own compact buffer, and the bands are interleaved back on the host.
-    const int gpus = opt.gpus;
-    std::vector<rt_context*> contexts(gpus, nullptr);
-    for (int g = 0; g < gpus; ++g) {
-        rt_status st = rt_create(g, &contexts[g]);
-        if (st != RT_OK) { std::fprintf(stderr, "rt_create(%d): %s\n", g, rt_status_string(st)); return 1; }
+    // One context per GPU (the counterpart of the worker threads of main.cpp:450-454).
+    std::vector<int> ordinals;
+    if (!opt.devices.empty()) {
+        for (size_t pos = 0; pos < opt.devices.size();) {
+            ordinals.push_back(std::atoi(opt.devices.c_str() + pos));
+            size_t comma = opt.devices.find(',', pos);
+            pos = comma == std::string::npos ? opt.devices.size() : comma + 1;
+        }
+    } else {
+        for (int g = 0; g < opt.gpus; ++g) ordinals.push_back(g);
+    }
+    std::vector<rt_context*> contexts(ordinals.size(), nullptr);
+    for (size_t g = 0; g < ordinals.size(); ++g) {
+        rt_status st = rt_create(ordinals[g], &contexts[g]);
+        if (st != RT_OK) { std::fprintf(stderr, "rt_create(%d): %s\n", ordinals[g], rt_status_string(st)); return 1; }
         st = rt_upload_world(contexts[g], &view);
         if (st != RT_OK) { std::fprintf(stderr, "rt_upload_world: %s\n", rt_error_string(contexts[g])); return 1; }
     }
 
-    std::vector<rt_render_params> params(gpus);
-    std::vector<std::vector<uint32_t>> shards(gpus);
-    std::vector<uint64_t> rays(gpus, 0);
-    std::vector<rt_status> status(gpus, RT_OK);
-    for (int g = 0; g < gpus; ++g) {
-        rt_render_params& p = params[g];
-        rt_default_params(&p, (uint32_t)opt.width, (uint32_t)opt.height, opt.spp);
-        p.max_bounces = opt.bounces;
-        p.seed_constant = opt.seed_constant;
-        p.rng_mode = opt.rng == "row" ? RT_RNG_ROW_SERIAL : RT_RNG_PIXEL;
-        p.lanes_per_pixel = opt.lanes_per_pixel;
-        p.intersect_mode = opt.intersect == "scalar" ? RT_INTERSECT_SCALAR : RT_INTERSECT_WIDE8;
-        if (gpus > 1) { p.band_rows = 8; p.band_index = (uint32_t)g; p.band_count = (uint32_t)gpus; }
-        shards[g].resize((size_t)rt_local_row_count(&p) * opt.width);
-    }
+    rt_render_params params;
+    rt_default_params(&params, (uint32_t)opt.width, (uint32_t)opt.height, opt.spp);
+    params.max_bounces = opt.bounces;
+    params.seed_constant = opt.seed_constant;
+    params.rng_mode = opt.rng == "row" ? RT_RNG_ROW_SERIAL : RT_RNG_PIXEL;
+    params.lanes_per_pixel = opt.lanes_per_pixel;
+    params.intersect_mode = opt.intersect == "scalar" ? RT_INTERSECT_SCALAR : RT_INTERSECT_WIDE8;
 
+    // The render: interleaved 8-row bands, one host thread per GPU, assembled in image.pixelData.
     auto start = std::chrono::steady_clock::now();
-    std::vector<std::thread> workers;
-    for (int g = 0; g < gpus; ++g)
-        workers.emplace_back([&, g] {
-            if (shards[g].empty()) return;
-            status[g] = rt_render(contexts[g], &params[g], shards[g].data(), nullptr, &rays[g]);
-        });
-    for (std::thread& t : workers) t.join();
-    for (int g = 0; g < gpus; ++g) {
-        if (status[g] != RT_OK) { std::fprintf(stderr, "rt_render on GPU %d: %s\n", g, rt_error_string(contexts[g])); return 1; }
-        uint32_t rows = rt_local_row_count(&params[g]);
-        for (uint32_t local = 0; local < rows; ++local)
-            std::memcpy(image.pixelData + (size_t)rt_global_row(&params[g], local) * opt.width,
-                        shards[g].data() + (size_t)local * opt.width, (size_t)opt.width * 4);
-    }
+    uint64_t rays = 0;
+    rt_status st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, image.pixelData, nullptr, &rays);
     auto end = std::chrono::steady_clock::now();
+    if (st != RT_OK) { std::fprintf(stderr, "render failed: %s\n", rt_error_string(contexts[0])); return 1; }
 
-    unsigned long long bouncesComputed = 0;
-    for (uint64_t r : rays) bouncesComputed += r;
+    unsigned long long bouncesComputed = rays;
     double timeElapsedMs = std::chrono::duration<double, std::milli>(end - start).count();
     // The reference's report lines (main.cpp:468-471).
     std::printf("Raytracing time: %.0fms\n", timeElapsedMs);

@@ -310,3 +310,23 @@ def test_packed_division_is_ieee_division():
     assert rc == 0
     assert tested.value == 4096 * 256 * 1024 * 2
     assert bad.value == 0, f"{bad.value} of {tested.value} quotients differ, e.g. a, b, div2, ieee = {first}"
+
+
+def test_render_multi_assembles_the_full_image(ctx, cornell):
+    """rt_render_multi with two contexts (here both on GPU 0, each with its own host thread) and with
+    the same context listed three times: interleaved 8-row bands reassemble into the single render."""
+    ctx.upload_world(cornell)
+    p = B.default_params(96, 50, 8, row_begin=3, row_end=47)
+    pix, rad, rays = ctx.render(p)
+    other = B.Context(0)
+    other.upload_world(cornell)
+    for group in ([ctx, other], [ctx, ctx, ctx], [other]):
+        mpix, mrad, mrays = B.render_multi(group, p)
+        assert mrays == rays
+        assert np.array_equal(mpix, pix) and np.array_equal(bits(mrad), bits(rad))
+    # more contexts than bands: the surplus ones own no rows
+    small = B.default_params(32, 10, 4)
+    spix, _, srays = ctx.render(small)
+    mpix, _, mrays = B.render_multi([ctx, other, ctx], small)
+    assert mrays == srays and np.array_equal(mpix, spix)
+    other.close()
