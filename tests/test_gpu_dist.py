@@ -1,0 +1,78 @@
+"""Two processes, both rendering with the HIP library (here on the same GPU), composed by
+raytracer_amd/distributed.py over gloo with host-side shards: everything of the multi-GPU path
+except the RCCL transport itself, which needs more than one GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from raytracer_amd import binding as B
+        from raytracer_amd import distributed as D
+        from raytracer_amd.host_scene import build_scene
+        ctx = B.Context(0)
+        ctx.upload_world(build_scene("cornell"))
+        base = B.default_params(120, 70, 16, lanes_per_pixel=4)
+
+        def render_rows(p, shard):
+            pix, _, rays = ctx.render(p, want_radiance=False)
+            shard[:pix.shape[0]] = torch.from_numpy(pix.view(np.int32))
+            return rays
+
+        img, rays = D.render_rows(render_rows, base, rank, world_size, "cpu")
+        total = D.sum_rays(torch.tensor([rays], dtype=torch.int64), world_size)
+        full = img.assemble()
+
+        def render_sum(p, radiance_sum):
+            _, rad, rays = ctx.render(p, want_pixels=False)
+            radiance_sum.copy_(torch.from_numpy(rad))
+            return rays
+
+        def resolve(radiance_sum, total_spp):
+            dev = torch.device("cuda", 0)
+            acc = radiance_sum.to(dev)
+            pixels = torch.zeros(acc.shape[:2], dtype=torch.int32, device=dev)
+            ctx.resolve_device(acc.data_ptr(), acc.shape[0] * acc.shape[1], total_spp, pixels.data_ptr(), None, None)
+            torch.cuda.synchronize(dev)
+            return pixels.cpu().numpy().view(np.uint32)
+
+        pixels, srays = D.render_samples(render_sum, resolve, base, rank, world_size, "cpu", B.FLAG_OUTPUT_SUM)
+        stotal = D.sum_rays(torch.tensor([srays], dtype=torch.int64), world_size)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "out.npz"), rows_image=full.numpy().view(np.uint32), rows_rays=total.numpy(),
+                     sample_pixels=pixels, sample_rays=stotal.numpy())
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_compose_the_single_gpu_image(tmp_path):
+    from raytracer_amd import binding as B
+    from raytracer_amd.host_scene import build_scene
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    out = np.load(tmp_path / "out.npz")
+    ctx = B.Context(0)
+    ctx.upload_world(build_scene("cornell"))
+    pix, _, rays = ctx.render(B.default_params(120, 70, 16, lanes_per_pixel=4))
+    assert np.array_equal(out["rows_image"], pix) and int(out["rows_rays"][0]) == rays
+    # two ranks x 16 spp with 4 batches each == one render of 32 spp with 8 batches
+    pix32, _, rays32 = ctx.render(B.default_params(120, 70, 32, lanes_per_pixel=8))
+    assert int(out["sample_rays"][0]) == rays32
+    assert np.array_equal(out["sample_pixels"], pix32)
+    ctx.close()
