@@ -196,6 +196,12 @@ rt_status rt_resolve_device(rt_context* context, const float* d_radiance_sum, ui
                             uint32_t total_samples, uint32_t* d_pixels, float* d_radiance_mean,
                             void* hip_stream);
 
+/* Same with HOST buffers, for callers that keep the accumulated sum in host memory (a progressive
+ * render that adds one pass after another, a sum loaded back from a checkpoint file).  pixels and
+ * radiance_mean may each be NULL.  Returns when the outputs are written. */
+rt_status rt_resolve(rt_context* context, const float* radiance_sum, uint64_t pixel_count,
+                     uint32_t total_samples, uint32_t* pixels, float* radiance_mean);
+
 /* Duration of the last render kernel launched with RT_FLAG_TIME_KERNEL, measured
  * with HIP events on the kernel's own stream.  Blocks until that kernel finished. */
 rt_status rt_last_kernel_ms(rt_context* context, float* out_ms);

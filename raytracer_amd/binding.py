@@ -27,7 +27,8 @@ FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL = 1, 2
 EXPORTS = (
     "rt_abi_version", "rt_status_string", "rt_create", "rt_destroy", "rt_error_string",
     "rt_get_device_info", "rt_default_params", "rt_local_row_count", "rt_global_row",
-    "rt_upload_world", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_last_kernel_ms",
+    "rt_upload_world", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_resolve",
+    "rt_last_kernel_ms",
 )
 
 
@@ -118,6 +119,8 @@ def load_library() -> C.CDLL:
                                   C.POINTER(C.c_uint64)]
     L.rt_resolve_device.restype = C.c_int
     L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_resolve.restype = C.c_int
+    L.rt_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
     L.rt_last_kernel_ms.restype = C.c_int
     L.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     if L.rt_abi_version() != 1:
@@ -222,6 +225,17 @@ class Context:
     def resolve_device(self, d_sum: int, pixel_count: int, total_samples: int, d_pixels: int | None,
                        d_mean: int | None, stream: int | None = None):
         self._check(self._lib.rt_resolve_device(self._h, d_sum, pixel_count, total_samples, d_pixels, d_mean, stream))
+
+    def resolve(self, radiance_sum: np.ndarray, total_samples: int, want_pixels=True, want_mean=True):
+        """Tonemap + pack of a host-resident sum [rows,W,3] f32: (pixels [rows,W] uint32, mean [rows,W,3] f32)."""
+        radiance_sum = np.ascontiguousarray(radiance_sum, dtype=np.float32)
+        rows, width, channels = radiance_sum.shape
+        if channels != 3:
+            raise ValueError("radiance_sum must be [rows, width, 3]")
+        pixels = np.zeros((rows, width), dtype=np.uint32) if want_pixels else None
+        mean = np.zeros((rows, width, 3), dtype=np.float32) if want_mean else None
+        self._check(self._lib.rt_resolve(self._h, _ptr(radiance_sum), rows * width, total_samples, _ptr(pixels), _ptr(mean)))
+        return pixels, mean
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)

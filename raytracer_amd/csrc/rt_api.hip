@@ -191,6 +191,18 @@ hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, fl
     return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
 }
 
+// Grow-only device buffers behind the entry points that return results in host memory.
+rt_status ensure_output_capacity(rt_context* ctx, size_t count) {
+    if (count <= ctx->pixel_capacity) return RT_OK;
+    if (ctx->d_pixels) { RT_HIP_CHECK(ctx, hipFree(ctx->d_pixels)); ctx->d_pixels = nullptr; }
+    if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
+    ctx->pixel_capacity = 0;
+    RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pixels, count * sizeof(uint32_t)));
+    RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
+    ctx->pixel_capacity = count;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -359,14 +371,8 @@ rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* p
     if (st != RT_OK) return st;
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t count = (size_t)L.kp.local_rows * L.kp.width;
-    if (count > ctx->pixel_capacity) {
-        if (ctx->d_pixels) { RT_HIP_CHECK(ctx, hipFree(ctx->d_pixels)); ctx->d_pixels = nullptr; }
-        if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
-        ctx->pixel_capacity = 0;
-        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pixels, count * sizeof(uint32_t)));
-        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
-        ctx->pixel_capacity = count;
-    }
+    st = ensure_output_capacity(ctx, count);
+    if (st != RT_OK) return st;
     st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, radiance ? ctx->d_radiance : nullptr,
                           reinterpret_cast<uint64_t*>(ctx->d_rays), nullptr);
     if (st != RT_OK) return st;
@@ -449,6 +455,33 @@ rt_status rt_resolve_device(rt_context* ctx, const float* d_sum, uint64_t pixel_
     hipLaunchKernelGGL(rt::resolve_kernel, dim3(blocks), dim3(rt::BLOCK_THREADS), 0, static_cast<hipStream_t>(hip_stream), d_sum,
                        pixel_count, (float)total_samples, d_pixels, d_mean);
     RT_HIP_CHECK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_count, uint32_t total_samples,
+                     uint32_t* pixels, float* radiance_mean) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!radiance_sum || pixel_count == 0 || total_samples == 0 || pixel_count > (1ull << 33))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve: bad sum pointer, pixel count or sample count");
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    rt_status st = ensure_output_capacity(ctx, (size_t)pixel_count);
+    if (st != RT_OK) return st;
+    float* d_sum = nullptr;
+    const size_t sum_bytes = (size_t)pixel_count * 3 * sizeof(float);
+    RT_HIP_CHECK(ctx, hipMalloc(&d_sum, sum_bytes));
+    hipError_t e = hipMemcpy(d_sum, radiance_sum, sum_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        st = rt_resolve_device(ctx, d_sum, pixel_count, total_samples, pixels ? ctx->d_pixels : nullptr,
+                               radiance_mean ? ctx->d_radiance : nullptr, nullptr);
+        if (st == RT_OK) e = hipStreamSynchronize(nullptr);
+        if (st == RT_OK && e == hipSuccess && pixels)
+            e = hipMemcpy(pixels, ctx->d_pixels, (size_t)pixel_count * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (st == RT_OK && e == hipSuccess && radiance_mean)
+            e = hipMemcpy(radiance_mean, ctx->d_radiance, sum_bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_sum);
+    if (st != RT_OK) return st;
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_resolve: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

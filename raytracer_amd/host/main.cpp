@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "rt_framebuffer.h"
 #include "rt_image.h"
 #include "rt_scene.h"
 
@@ -32,6 +33,11 @@ struct Options {
     int gpus = 1;
     std::string devices;                     // explicit device ordinals, e.g. "0,1,2,3" (overrides --gpus)
     std::string out = "render.bmp";
+    // Progressive rendering: `passes` renders of `spp` samples each are summed in a float
+    // framebuffer, which can be stored after every pass and picked up again later.
+    unsigned passes = 1;
+    std::string checkpoint;                  // RTFB file written after every pass
+    std::string resume;                      // RTFB file to continue from
 };
 
 void Usage() {
@@ -39,7 +45,8 @@ void Usage() {
                  "usage: raytracer [--scene cornell|spheres|random_spheres|glass_spheres|FILE.rtsc] [--count N] [--scene-seed S]\n"
                  "                 [--width W] [--height H] [--spp N] [--bounces N] [--seed-constant N]\n"
                  "                 [--rng pixel|row] [--lanes-per-pixel N] [--intersect wide|scalar]\n"
-                 "                 [--gpus N | --devices 0,1,...] [--out FILE.bmp]\n");
+                 "                 [--gpus N | --devices 0,1,...] [--out FILE.bmp]\n"
+                 "                 [--passes N] [--checkpoint FILE.rtfb] [--resume FILE.rtfb]\n");
 }
 
 bool Parse(int argc, char** argv, Options* o) {
@@ -63,9 +70,12 @@ bool Parse(int argc, char** argv, Options* o) {
         else if (a == "--gpus") o->gpus = std::atoi(v);
         else if (a == "--devices") o->devices = v;
         else if (a == "--out") o->out = v;
+        else if (a == "--passes") o->passes = (unsigned)std::strtoul(v, nullptr, 0);
+        else if (a == "--checkpoint") o->checkpoint = v;
+        else if (a == "--resume") o->resume = v;
         else return false;
     }
-    return o->width > 0 && o->height > 0 && o->gpus > 0;
+    return o->width > 0 && o->height > 0 && o->gpus > 0 && o->passes > 0;
 }
 
 World* BuildWorld(const Options& o) {
@@ -117,7 +127,53 @@ int main(int argc, char** argv) {
     // The render: interleaved 8-row bands, one host thread per GPU, assembled in image.pixelData.
     auto start = std::chrono::steady_clock::now();
     uint64_t rays = 0;
-    rt_status st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, image.pixelData, nullptr, &rays);
+    rt_status st = RT_OK;
+    const bool progressive = opt.passes > 1 || !opt.checkpoint.empty() || !opt.resume.empty();
+    if (!progressive) {
+        st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, image.pixelData, nullptr, &rays);
+    } else {
+        // Every pass draws fresh sample batches (batch_offset), returns its un-normalised sum, and the
+        // sums are added in pass order; the image is the resolve of the total (the color / sampleSize
+        // and pack of main.cpp:393 applied once, at the end).
+        if (params.rng_mode != RT_RNG_PIXEL) {
+            std::fprintf(stderr, "--passes/--checkpoint/--resume need --rng pixel: a row-serial stream has no second batch\n");
+            return 2;
+        }
+        Accumulator acc;
+        acc.Reset((uint32_t)opt.width, (uint32_t)opt.height);
+        acc.lanes_per_pixel = params.lanes_per_pixel;
+        acc.scene_hash = HashWorld(view);
+        acc.settings_hash = HashSettings(params);
+        if (!opt.resume.empty()) {
+            Accumulator loaded;
+            std::string why;
+            if (!ReadAccumulatorFile(opt.resume.c_str(), &loaded, &why)) { std::fprintf(stderr, "%s\n", why.c_str()); return 1; }
+            if (loaded.width != acc.width || loaded.height != acc.height || loaded.lanes_per_pixel != acc.lanes_per_pixel ||
+                loaded.scene_hash != acc.scene_hash || loaded.settings_hash != acc.settings_hash) {
+                std::fprintf(stderr, "%s was rendered with another scene, image size or settings\n", opt.resume.c_str());
+                return 1;
+            }
+            acc = std::move(loaded);
+            std::printf("Resumed at %u samples per pixel\n", acc.samples);
+        }
+        std::vector<float> pass_sum(acc.sum.size());
+        params.flags |= RT_FLAG_OUTPUT_SUM;
+        for (unsigned pass = 0; pass < opt.passes && st == RT_OK; ++pass) {
+            params.batch_offset = acc.next_batch;
+            uint64_t pass_rays = 0;
+            st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, nullptr, pass_sum.data(), &pass_rays);
+            if (st != RT_OK) break;
+            acc.AddPass(pass_sum.data(), opt.spp, pass_rays);
+            rays += pass_rays;
+            if (!opt.checkpoint.empty() && !WriteAccumulatorFile(acc, opt.checkpoint.c_str())) {
+                std::fprintf(stderr, "cannot write %s\n", opt.checkpoint.c_str());
+                return 1;
+            }
+            std::printf("Pass %u/%u: %u samples per pixel\n", pass + 1, opt.passes, acc.samples);
+        }
+        if (st == RT_OK)
+            st = rt_resolve(contexts[0], acc.sum.data(), (uint64_t)opt.width * (uint64_t)opt.height, acc.samples, image.pixelData, nullptr);
+    }
     auto end = std::chrono::steady_clock::now();
     if (st != RT_OK) { std::fprintf(stderr, "render failed: %s\n", rt_error_string(contexts[0])); return 1; }
 

@@ -22,6 +22,14 @@ void rth_world_view(const rth_world* world, rt_world* out);
 int rth_world_write(const rth_world* world, const char* path);   /* 0 on success */
 int rth_write_bmp(const char* path, const uint32_t* pixels, int32_t width, int32_t height); /* 0 on success */
 
+/* Resumable float framebuffer files (rt_framebuffer.h).  The header travels as 8 x uint64:
+ * width, height, samples, next_batch, lanes_per_pixel, scene_hash, settings_hash, rays. */
+uint64_t rth_world_hash(const rth_world* world);
+uint64_t rth_settings_hash(const rt_render_params* params);
+int rth_framebuffer_write(const char* path, const uint64_t header[8], const float* sum);       /* 0 on success */
+int rth_framebuffer_read_header(const char* path, uint64_t header[8]);                          /* 0 on success */
+int rth_framebuffer_read(const char* path, uint64_t header[8], float* sum, uint64_t capacity);  /* capacity in floats */
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,12 +7,14 @@ import pathlib
 import numpy as np
 
 from . import scene_io
-from .binding import World
+from .binding import RenderParams, World
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librt_host.so"
 
-EXPORTS = ("rth_world_create", "rth_world_destroy", "rth_world_view", "rth_world_write", "rth_write_bmp")
+EXPORTS = ("rth_world_create", "rth_world_destroy", "rth_world_view", "rth_world_write", "rth_write_bmp",
+           "rth_world_hash", "rth_settings_hash", "rth_framebuffer_write", "rth_framebuffer_read_header",
+           "rth_framebuffer_read")
 
 _lib = None
 
@@ -33,6 +35,16 @@ def load_library() -> C.CDLL:
         L.rth_world_write.argtypes = [C.c_void_p, C.c_char_p]
         L.rth_write_bmp.restype = C.c_int
         L.rth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rth_world_hash.restype = C.c_uint64
+        L.rth_world_hash.argtypes = [C.c_void_p]
+        L.rth_settings_hash.restype = C.c_uint64
+        L.rth_settings_hash.argtypes = [C.POINTER(RenderParams)]
+        L.rth_framebuffer_write.restype = C.c_int
+        L.rth_framebuffer_write.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_void_p]
+        L.rth_framebuffer_read_header.restype = C.c_int
+        L.rth_framebuffer_read_header.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+        L.rth_framebuffer_read.restype = C.c_int
+        L.rth_framebuffer_read.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -68,3 +80,19 @@ def write_bmp(path, pixels: np.ndarray) -> None:
     h, w = pixels.shape
     if load_library().rth_write_bmp(str(path).encode(), pixels.ctypes.data_as(C.c_void_p), w, h) != 0:
         raise OSError(f"cannot write {path}")
+
+
+def world_hash(name: str, count: int = 0, seed: int = 1) -> int:
+    """HashWorld of a scene built by name (the value the driver stores in its checkpoint files)."""
+    L = load_library()
+    h = L.rth_world_create(str(name).encode(), count, seed)
+    if not h:
+        raise ValueError(f"unknown scene or unreadable scene file: {name!r}")
+    try:
+        return int(L.rth_world_hash(h))
+    finally:
+        L.rth_world_destroy(h)
+
+
+def settings_hash(params: RenderParams) -> int:
+    return int(load_library().rth_settings_hash(C.byref(params)))

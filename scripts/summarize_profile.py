@@ -10,10 +10,11 @@ import sys
 
 src, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
 rays = int(sys.argv[4]) if len(sys.argv) > 4 else 1454628861
-flop_per_ray = 887
+flop_per_ray = float(sys.argv[5]) if len(sys.argv) > 5 else 887
+command = sys.argv[6] if len(sys.argv) > 6 else "--scene cornell --width 1920 --height 1080 --spp 256"
 
 lines = [f"# {title}", "", "Command (per pass): `rocprofv3 <--kernel-trace --stats | --pmc ...> -- raytracer_amd/bin/raytracer "
-         "--scene cornell --width 1920 --height 1080 --spp 256` (scripts/profile_gpu.sh).", ""]
+         f"{command}` (scripts/profile_gpu.sh).", ""]
 stats = list(csv.DictReader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))))
 lines += ["## rocprofv3 --kernel-trace --stats", "", "| kernel | calls | total ns | average ns | % |", "|---|---|---|---|---|"]
 kernel_ns = None

@@ -1,0 +1,184 @@
+"""Resumable float framebuffer (RTFB files) and progressive rendering: file format on the CPU,
+resume equivalence on the GPU."""
+import pathlib
+import struct
+import subprocess
+
+import ctypes as C
+import numpy as np
+import pytest
+
+from raytracer_amd import binding as B
+from raytracer_amd import framebuffer as F
+from raytracer_amd import host_scene as H
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+DRIVER = ROOT / "raytracer_amd" / "bin" / "raytracer"
+
+
+def _acc(w=7, h=5, seed=3):
+    rng = np.random.default_rng(seed)
+    return F.Accumulator(w, h, samples=48, next_batch=12, lanes_per_pixel=4, scene_hash=0x0123456789ABCDEF,
+                         settings_hash=0xFEDCBA9876543210, rays=(1 << 40) + 17,
+                         sum=rng.random((h, w, 3), dtype=np.float32) * 100)
+
+
+def test_python_round_trip_and_layout(tmp_path):
+    a = _acc()
+    path = tmp_path / "a.rtfb"
+    a.write(path)
+    data = path.read_bytes()
+    assert len(data) == 64 + 7 * 5 * 12 and data[:4] == b"RTFB"
+    assert struct.unpack_from("<7I3Q", data, 4) == (1, 7, 5, 3, 48, 12, 4, a.scene_hash, a.settings_hash, a.rays)
+    assert data[56:64] == bytes(8)
+    assert np.frombuffer(data, dtype="<f4", offset=64).tobytes() == a.sum.tobytes()
+    b = F.Accumulator.read(path)
+    assert (b.width, b.height, b.samples, b.next_batch, b.lanes_per_pixel, b.scene_hash, b.settings_hash, b.rays) == \
+           (7, 5, 48, 12, 4, a.scene_hash, a.settings_hash, a.rays)
+    assert b.sum.tobytes() == a.sum.tobytes()
+    assert not (tmp_path / "a.rtfb.tmp").exists()
+
+
+def test_cpp_and_python_write_the_same_bytes(tmp_path):
+    L = H.load_library()
+    a = _acc()
+    a.write(tmp_path / "py.rtfb")
+    header = (C.c_uint64 * 8)(a.width, a.height, a.samples, a.next_batch, a.lanes_per_pixel, a.scene_hash, a.settings_hash, a.rays)
+    assert L.rth_framebuffer_write(str(tmp_path / "cpp.rtfb").encode(), header, a.sum.ctypes.data_as(C.c_void_p)) == 0
+    assert (tmp_path / "py.rtfb").read_bytes() == (tmp_path / "cpp.rtfb").read_bytes()
+    got = (C.c_uint64 * 8)()
+    out = np.zeros_like(a.sum)
+    assert L.rth_framebuffer_read(str(tmp_path / "py.rtfb").encode(), got, out.ctypes.data_as(C.c_void_p), out.size) == 0
+    assert list(got) == list(header) and out.tobytes() == a.sum.tobytes()
+    assert L.rth_framebuffer_read(str(tmp_path / "py.rtfb").encode(), got, out.ctypes.data_as(C.c_void_p), out.size - 1) == 2
+    assert L.rth_framebuffer_read_header(str(tmp_path / "py.rtfb").encode(), got) == 0 and got[2] == 48
+
+
+def test_malformed_files_are_refused(tmp_path):
+    L = H.load_library()
+    a = _acc()
+    good = tmp_path / "good.rtfb"
+    a.write(good)
+    data = good.read_bytes()
+    cases = {
+        "short.rtfb": data[:40],
+        "magic.rtfb": b"RTSC" + data[4:],
+        "version.rtfb": data[:4] + struct.pack("<I", 2) + data[8:],
+        "channels.rtfb": data[:16] + struct.pack("<I", 4) + data[20:],
+        "zero.rtfb": data[:8] + struct.pack("<I", 0) + data[12:],
+        "truncated.rtfb": data[:-4],
+        "trailing.rtfb": data + b"\0",
+    }
+    got = (C.c_uint64 * 8)()
+    for name, blob in cases.items():
+        path = tmp_path / name
+        path.write_bytes(blob)
+        with pytest.raises(ValueError):
+            F.Accumulator.read(path)
+        assert L.rth_framebuffer_read_header(str(path).encode(), got) == 1, name
+    assert L.rth_framebuffer_read_header(str(tmp_path / "absent.rtfb").encode(), got) == 1
+    with pytest.raises(ValueError):
+        F.Accumulator(4, 4, sum=np.zeros((4, 5, 3), dtype=np.float32))
+
+
+def test_hashes_agree_between_cpp_and_python():
+    for name, count in (("cornell", 0), ("spheres", 0), ("random_spheres", 61), ("glass_spheres", 3)):
+        assert F.scene_hash(H.build_scene(name, count, 5)) == H.world_hash(name, count, 5)
+    assert H.world_hash("random_spheres", 61, 5) != H.world_hash("random_spheres", 61, 6)
+    p = B.default_params(320, 180, 64, lanes_per_pixel=4, max_bounces=5)
+    assert F.settings_hash(p) == H.settings_hash(p)
+    q = B.default_params(320, 180, 64, lanes_per_pixel=4, max_bounces=6)
+    assert F.settings_hash(q) != F.settings_hash(p)
+    q = B.default_params(320, 180, 64, lanes_per_pixel=4, max_bounces=5)
+    q.batch_offset, q.flags = 12, B.FLAG_OUTPUT_SUM     # what changes from pass to pass is not part of the hash
+    assert F.settings_hash(q) == F.settings_hash(p)
+
+
+def test_add_pass_is_a_float32_sum_in_pass_order():
+    acc = F.Accumulator(3, 2, lanes_per_pixel=2)
+    parts = [np.full((2, 3, 3), v, dtype=np.float32) for v in (1e8, 1.0, -1e8)]
+    for i, part in enumerate(parts):
+        acc.add_pass(part, 16, 10 + i)
+    assert (acc.samples, acc.next_batch, acc.rays) == (48, 6, 33)
+    assert (acc.sum == np.float32(np.float32(np.float32(1e8) + np.float32(1.0)) - np.float32(1e8))).all()
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.gpu
+def test_progressive_passes_resume_bit_exactly(tmp_path, spheres):
+    """4 passes in one go == 2 passes, checkpoint to disk, reload, 2 more passes: same sums, rays, pixels;
+    a 1-pass accumulator resolves to the pixels of the plain render."""
+    with B.Context(0) as ctx:
+        ctx.upload_world(spheres)
+        p = B.default_params(96, 54, 16, lanes_per_pixel=4)
+        straight = F.render_progressive(ctx, p, 4)
+        first = F.render_progressive(ctx, p, 2, checkpoint=tmp_path / "half.rtfb")
+        loaded = F.Accumulator.read(tmp_path / "half.rtfb")
+        assert (loaded.samples, loaded.next_batch, loaded.rays) == (32, 8, first.rays)
+        assert loaded.settings_hash == H.settings_hash(p)
+        resumed = F.render_progressive(ctx, p, 2, accumulator=loaded)
+        assert (resumed.samples, resumed.next_batch, resumed.rays) == (64, 16, straight.rays)
+        assert np.array_equal(_bits(resumed.sum), _bits(straight.sum))
+        assert (p.flags, p.batch_offset) == (0, 0)
+        pix_a, mean_a = ctx.resolve(straight.sum, straight.samples)
+        pix_b, _ = ctx.resolve(resumed.sum, resumed.samples)
+        assert np.array_equal(pix_a, pix_b)
+        # passes are independent estimates: pass 1 and pass 2 differ, and 64 spp is closer to 4096 spp than 16 spp is
+        one = F.render_progressive(ctx, p, 1)
+        plain_pix, plain_mean, plain_rays = ctx.render(p)
+        pix_one, mean_one = ctx.resolve(one.sum, one.samples)
+        assert one.rays == plain_rays and np.array_equal(pix_one, plain_pix) and np.array_equal(_bits(mean_one), _bits(plain_mean))
+        _, truth, _ = ctx.render(B.default_params(96, 54, 4096, lanes_per_pixel=4, batch_offset=1 << 20))
+        err16 = np.sqrt(np.mean((np.minimum(plain_mean, 1) - np.minimum(truth, 1)) ** 2))
+        err64 = np.sqrt(np.mean((np.minimum(mean_a, 1) - np.minimum(truth, 1)) ** 2))
+        assert err64 < 0.7 * err16
+        with pytest.raises(ValueError):
+            F.render_progressive(ctx, B.default_params(96, 54, 16, rng_mode=B.RNG_ROW_SERIAL), 2)
+        with pytest.raises(ValueError):
+            F.render_progressive(ctx, B.default_params(96, 54, 16, lanes_per_pixel=2), 1, accumulator=loaded)
+        with pytest.raises(B.RtError):
+            ctx.resolve(straight.sum, 0)
+
+
+@pytest.mark.gpu
+def test_driver_checkpoint_and_resume(tmp_path):
+    """raytracer --passes / --checkpoint / --resume: an interrupted render continued from its file gives the
+    same BMP as the uninterrupted one, and the same sums as the library; a file from another scene is refused."""
+    common = ["--scene", "cornell", "--width", "128", "--height", "72", "--spp", "8", "--lanes-per-pixel", "2"]
+    run = lambda extra: subprocess.run([str(DRIVER)] + common + extra, capture_output=True, text=True, timeout=120)
+    full = run(["--passes", "3", "--checkpoint", str(tmp_path / "full.rtfb"), "--out", str(tmp_path / "full.bmp")])
+    assert full.returncode == 0, full.stderr
+    assert "Pass 3/3: 24 samples per pixel" in full.stdout
+    part = run(["--passes", "1", "--checkpoint", str(tmp_path / "part.rtfb"), "--out", str(tmp_path / "part.bmp")])
+    assert part.returncode == 0, part.stderr
+    rest = run(["--passes", "2", "--resume", str(tmp_path / "part.rtfb"), "--checkpoint", str(tmp_path / "rest.rtfb"),
+                "--out", str(tmp_path / "rest.bmp")])
+    assert rest.returncode == 0, rest.stderr
+    assert "Resumed at 8 samples per pixel" in rest.stdout
+    assert (tmp_path / "rest.bmp").read_bytes() == (tmp_path / "full.bmp").read_bytes()
+    assert (tmp_path / "rest.rtfb").read_bytes() == (tmp_path / "full.rtfb").read_bytes()
+    assert (tmp_path / "part.bmp").read_bytes() != (tmp_path / "full.bmp").read_bytes()
+
+    acc = F.Accumulator.read(tmp_path / "full.rtfb")
+    with B.Context(0) as ctx:
+        ctx.upload_world(H.build_scene("cornell"))
+        p = B.default_params(128, 72, 8, lanes_per_pixel=2)
+        mine = F.render_progressive(ctx, p, 3)
+        pixels, _ = ctx.resolve(mine.sum, mine.samples)
+    assert (acc.samples, acc.next_batch, acc.rays) == (mine.samples, mine.next_batch, mine.rays)
+    assert acc.scene_hash == H.world_hash("cornell") and acc.settings_hash == H.settings_hash(p)
+    assert np.array_equal(_bits(acc.sum), _bits(mine.sum))
+    bmp = np.frombuffer((tmp_path / "full.bmp").read_bytes(), dtype=np.uint32, offset=54).reshape(72, 128)
+    assert np.array_equal(bmp, pixels)
+
+    other = subprocess.run([str(DRIVER), "--scene", "spheres", "--width", "128", "--height", "72", "--spp", "8",
+                            "--lanes-per-pixel", "2", "--resume", str(tmp_path / "part.rtfb"), "--out", str(tmp_path / "x.bmp")],
+                           capture_output=True, text=True, timeout=120)
+    assert other.returncode == 1 and "another scene" in other.stderr
+    row = run(["--rng", "row", "--passes", "2", "--out", str(tmp_path / "y.bmp")])
+    assert row.returncode == 2 and "--rng pixel" in row.stderr
