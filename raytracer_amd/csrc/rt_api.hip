@@ -5,6 +5,7 @@
 // are computed with the same once-rounded float operations as main.cpp:350-368.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -323,6 +324,26 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
         if (w->spheres[i].material_index >= w->material_count) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sphere %u: material index out of range", i);
     for (uint32_t i = 0; i < w->rectangle_count; ++i)
         if (w->rectangles[i].material_index >= w->material_count) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rectangle %u: material index out of range", i);
+
+    // Every scene value must be finite and of magnitude <= 1e18: with such values no intermediate of
+    // the kernel's shortened arithmetic forms (see rt_kernels.hpp) overflows, which is what their
+    // equality with the reference's operations rests on.  (The reference itself turns larger values
+    // into inf/NaN rays.)
+    auto bounded = [](const float* v, size_t n) {
+        for (size_t i = 0; i < n; ++i)
+            if (!(std::fabs(v[i]) <= 1.0e18f)) return false;   // false for NaN too
+        return true;
+    };
+    for (uint32_t i = 0; i < w->material_count; ++i)
+        if (!bounded(w->materials[i].color, 8)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "material %u: non-finite or huge value", i);
+    for (uint32_t i = 0; i < w->plane_count; ++i)
+        if (!bounded(w->planes[i].normal, 4)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "plane %u: non-finite or huge value", i);
+    for (uint32_t i = 0; i < w->sphere_count; ++i)
+        if (!bounded(w->spheres[i].position, 4)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sphere %u: non-finite or huge value", i);
+    for (uint32_t i = 0; i < w->rectangle_count; ++i)
+        if (!bounded(&w->rectangles[i].inverse_transform[0][0], 19))
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rectangle %u: non-finite or huge value", i);
+    if (!bounded(w->camera->position, 12)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera: non-finite or huge value");
 
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;

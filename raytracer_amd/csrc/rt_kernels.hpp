@@ -56,9 +56,30 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ float dot_fma(V3 a, V3 b) {
     return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z));
 }
+// 1.0f / sqrtf(x) with both operations correctly rounded, i.e. exactly what the two library calls
+// give.  For x in [2^-96, 2^96] the compiler's operand scaling, class tests and division fix-up are
+// the identity, and the remaining work is done here without them: the 1-ulp hardware square root is
+// moved to the correctly rounded neighbour by the sign of two residuals, and the reciprocal is the
+// division refinement of div2 with numerator 1 (the first quotient estimate is the refined reciprocal
+// itself).  Other arguments (zero, denormal, huge, inf, NaN) take the library forms.  The device
+// self-test compares the two paths over every float of the fast range.
+__device__ __forceinline__ float inv_sqrt_exact(float x) {
+    if (__float_as_uint(x) - 0x0F800000u <= 0x6F800000u - 0x0F800000u) {   // 2^-96 <= x <= 2^96
+        const float s = __builtin_amdgcn_sqrtf(x);
+        const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+        float root = s;
+        if (__builtin_fmaf(-s_dn, s, x) <= 0.0f) root = s_dn;
+        if (__builtin_fmaf(-s_up, s, x) > 0.0f) root = s_up;
+        float y = __builtin_amdgcn_rcpf(root);
+        y = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
+        float q = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
+        return __builtin_fmaf(__builtin_fmaf(-root, q, 1.0f), y, q);
+    }
+    return 1.0f / __builtin_sqrtf(x);
+}
 // math_vector.h:167-171: v * (1 / sqrtf(v.v)).
 __device__ __forceinline__ V3 normalize(V3 v) {
-    const float f = 1.0f / __builtin_sqrtf(dot(v, v));
+    const float f = inv_sqrt_exact(dot(v, v));
     return mk(v.x * f, v.y * f, v.z * f);
 }
 __device__ __forceinline__ V3 load3(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -157,6 +178,30 @@ struct SceneView {
 // World intersection.  best_id: 0 = miss, 1+i plane i, 1+np+k sphere slot k,
 // 1+np+ns+k rectangle slot k (slots in the image's order).
 struct Closest { float t; uint32_t id; };
+
+// Closest-hit update of the rectangle test (main.cpp:121-127 / 229-237):
+//   if (|hx| <= 1 && |hy| <= 1 && t < best_t && t > min_hit) { best_t = t; best_id = id; }
+// written as four v_cmpx that narrow EXEC and two moves under the narrowed mask, instead of the
+// compiler's four compares into scalar masks, three scalar ANDs and two v_cndmask: same predicate,
+// same NaN behaviour (every comparison is false on NaN), about a quarter fewer issue cycles.  EXEC is
+// saved and restored inside the block, so it may sit in divergent code.  `min_hit` and `id` are
+// wave-uniform (scalar registers).
+__device__ __forceinline__ void update_closest_rect(float hx, float hy, float t, float min_hit, uint32_t id, float& best_t,
+                                                    uint32_t& best_id) {
+    unsigned long long saved_exec;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_lt_f32_e32 %[t], %[best]\n\t"
+        "v_cmpx_ge_f32_e64 exec, 1.0, |%[hx]|\n\t"
+        "v_cmpx_ge_f32_e64 exec, 1.0, |%[hy]|\n\t"
+        "v_cmpx_lt_f32_e32 %[minhit], %[t]\n\t"
+        "v_mov_b32_e32 %[best], %[t]\n\t"
+        "v_mov_b32_e32 %[bid], %[id]\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [save] "=&s"(saved_exec), [best] "+v"(best_t), [bid] "+v"(best_id)
+        : [t] "v"(t), [hx] "v"(hx), [hy] "v"(hy), [minhit] "s"(min_hit), [id] "s"(id)
+        : "vcc");
+}
 
 template <int IMODE, bool MIXED>
 __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol) {
@@ -258,6 +303,10 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
             const F2 lo = which ? b_lo : a_lo, ld = which ? b_ld : a_ld;
             const float t = which ? t2.y : t2.x;
             const F2 h = lo + ld * splat(t);
+            if (!MIXED) {
+                update_closest_rect(h.x, h.y, t, min_hit, rect_base + 2 * pair + which, best_t, best_id);
+                continue;
+            }
             bool closer = t < best_t;
             if (MIXED && IMODE == RT_INTERSECT_WIDE8) {
                 // A sphere and a rectangle at exactly the same t: the reference keeps the lower
@@ -300,7 +349,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
             // (simd_avx2.h:139-144, relative error <= 1.5 * 2^-12, hardware specific); this is the
             // correctly rounded 1 / sqrt.
             V3 v = mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)) - c;
-            float f = 1.0f / __builtin_sqrtf(dot_fma(v, v));
+            float f = inv_sqrt_exact(dot_fma(v, v));
             h.normal = mk(v.x * f, v.y * f, v.z * f);
         } else {
             V3 hp = o + d * t;                 // main.cpp:203-204
@@ -489,22 +538,30 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 ro = ro + rd * c.t;
 
                 V3 n = h.normal;
-                V3 mirror = rd - n * dot(n, rd) * 2.0f;
                 // g++ evaluates the constructor arguments right to left: z, y, x (main.cpp:291-294).
                 float rz = random_bilateral(state);
                 float ry = random_bilateral(state);
                 float rx = random_bilateral(state);
-                V3 random_bounce = n + mk(rx, ry, rz);
-                float refl = m1.w;
                 // The reference normalises the reflected and the refracted candidate and then picks
                 // one (main.cpp:295-322); picking first and normalising once gives the same vector.
-                V3 reflected = random_bounce * (1.0f - refl) + mirror * refl;   // Lerp, math_util.h:24-26
-                float fresnel = 1.0f;
-                V3 refracted = reflected;
-                if (m0.w != 0.0f) {
-                    if (refract(rd, n, m0.w, m2.x, refracted)) fresnel = schlick(rd, n, m2.y);
+                V3 reflected = n + mk(rx, ry, rz);
+                const float refl = m1.w;
+                if (refl != 0.0f) {
+                    V3 mirror = rd - n * dot(n, rd) * 2.0f;
+                    reflected = reflected * (1.0f - refl) + mirror * refl;   // Lerp, math_util.h:24-26
                 }
-                next_dir = (random_unilateral(state) <= fresnel) ? reflected : refracted;
+                // refl == 0 (diffuse): Lerp gives random_bounce * 1 + mirror * 0 = random_bounce + (+-0), which is
+                // random_bounce bit for bit: the sum n + r is never -0 (r is never -0), and mirror is finite
+                // (unit rd, scene values bounded at upload), so the block is skipped by waves with no mirror hit.
+                const uint32_t pick = xorshift32(state);   // RandomUnilateral of main.cpp:318, drawn for every material
+                next_dir = reflected;
+                if (m0.w != 0.0f) {
+                    float fresnel = 1.0f;
+                    V3 refracted = reflected;
+                    if (refract(rd, n, m0.w, m2.x, refracted)) fresnel = schlick(rd, n, m2.y);
+                    if (!((float)pick * 0x1.0p-32f <= fresnel)) next_dir = refracted;
+                }
+                // Opaque materials: both candidates are `reflected`, whatever the draw says.
                 if (bounce >= p.max_bounces) in_path = false;
             } else {
                 const float4 sky = *reinterpret_cast<const float4*>(sv.f + sv.off_mats + 4);   // materials[0].emit

@@ -47,6 +47,24 @@ __global__ void div2_kernel(uint64_t seed, uint32_t per_thread, uint32_t exp_lo,
     atomicAdd(&counts[1], 2ull * per_thread);
 }
 
+// Every float whose bit pattern lies in [first, first + count): inv_sqrt_exact against the two library
+// operations it stands for.  NaN results count as equal to each other.
+__global__ void inv_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* counts, float* first_bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float x = __uint_as_float(first + (uint32_t)i);
+        const float fast = rt::inv_sqrt_exact(x);
+        const float slow = 1.0f / __builtin_sqrtf(x);
+        const bool same = __float_as_uint(fast) == __float_as_uint(slow) || (fast != fast && slow != slow);
+        if (!same) {
+            if (bad == 0 && atomicAdd(&counts[2], 1ull) == 0) { first_bad[0] = x; first_bad[1] = fast; first_bad[2] = slow; }
+            ++bad;
+        }
+    }
+    atomicAdd(&counts[0], bad);
+}
+
 }  // namespace
 
 extern "C" {
@@ -73,6 +91,29 @@ int rt_selftest_div2(uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32
     (void)hipFree(d_bad);
     if (mismatches) *mismatches = h[0];
     if (tested) *tested = h[1];
+    return (int)e;
+}
+
+// Compares rt::inv_sqrt_exact with 1.0f / sqrtf on the `count` floats whose bit patterns start at
+// `first_bits` (count = 2^32 from 0 covers every float).  Returns 0 on success; *mismatches receives the
+// number of differing results, first_bad[3] = {x, inv_sqrt_exact, library} of one of them.
+int rt_selftest_inv_sqrt(uint32_t first_bits, uint64_t count, uint64_t* mismatches, float* first_bad) {
+    unsigned long long* d_counts = nullptr;
+    float* d_bad = nullptr;
+    hipError_t e = hipMalloc(&d_counts, 3 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    e = hipMalloc(&d_bad, 4 * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(d_counts); return (int)e; }
+    (void)hipMemset(d_counts, 0, 3 * sizeof(unsigned long long));
+    (void)hipMemset(d_bad, 0, 4 * sizeof(float));
+    hipLaunchKernelGGL(inv_sqrt_kernel, dim3(8192), dim3(256), 0, 0, first_bits, count, d_counts, d_bad);
+    e = hipDeviceSynchronize();
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d_counts, sizeof h, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && first_bad) e = hipMemcpy(first_bad, d_bad, 3 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_bad);
+    if (mismatches) *mismatches = h[0];
     return (int)e;
 }
 

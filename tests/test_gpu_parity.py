@@ -279,6 +279,16 @@ def test_errors(ctx, cornell):
     with pytest.raises(B.RtError) as e:
         ctx.upload_world(big)
     assert e.value.status == 5                                  # RT_ERR_TOO_LARGE
+    # non-finite or huge scene values are refused at upload (the kernel's arithmetic forms assume bounded input)
+    import copy
+    for field, index, value in (("rectangles", ("inverse_transform", 3, (1, 2)), np.nan), ("rectangles", ("normal", 0, 1), np.inf),
+                                ("materials", ("emit_color", 2, 0), -np.inf), ("camera", ("position", 0, 2), 2e18)):
+        broken = copy.deepcopy(cornell)
+        name, row, col = index
+        getattr(broken, field)[name][row][col] = value
+        with pytest.raises(B.RtError) as e:
+            ctx.upload_world(broken)
+        assert e.value.status == 1 and "non-finite or huge" in str(e.value), field
     ctx.upload_world(cornell)                                   # the context is still usable
     ctx.render(B.default_params(16, 16, 4))
 
@@ -310,6 +320,21 @@ def test_packed_division_is_ieee_division():
     assert rc == 0
     assert tested.value == 4096 * 256 * 1024 * 2
     assert bad.value == 0, f"{bad.value} of {tested.value} quotients differ, e.g. a, b, div2, ieee = {first}"
+
+
+def test_inverse_length_equals_the_library_operations_on_every_float():
+    """rt::inv_sqrt_exact (hardware sqrt moved to the correctly rounded neighbour + unscaled reciprocal
+    refinement) against 1.0f / sqrtf(x) for all 2^32 bit patterns: the fast range, and the zero, denormal,
+    huge, negative, inf and NaN arguments that take the library forms."""
+    import pathlib
+    lib = C.CDLL(str(pathlib.Path(B.LIB_PATH).with_name("librt_selftest.so")))
+    lib.rt_selftest_inv_sqrt.restype = C.c_int
+    lib.rt_selftest_inv_sqrt.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    bad = C.c_uint64(0)
+    first = np.zeros(3, dtype=np.float32)
+    rc = lib.rt_selftest_inv_sqrt(0, 1 << 32, C.byref(bad), first.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert bad.value == 0, f"{bad.value} arguments differ, e.g. x, inv_sqrt_exact, library = {first}"
 
 
 def test_render_multi_assembles_the_full_image(ctx, cornell):
