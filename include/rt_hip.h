@@ -37,7 +37,7 @@ typedef enum rt_status {
     RT_ERR_NO_DEVICE = 2,      /* no HIP device, or ordinal out of range */
     RT_ERR_HIP = 3,            /* a HIP runtime call failed; see rt_error_string */
     RT_ERR_NO_WORLD = 4,       /* rt_render* before rt_upload_world */
-    RT_ERR_TOO_LARGE = 5,      /* scene does not fit the per-workgroup LDS budget */
+    RT_ERR_TOO_LARGE = 5,      /* planes + rectangles + materials exceed the LDS of one workgroup (spheres are not limited) */
     RT_ERR_OUT_OF_MEMORY = 6
 } rt_status;
 

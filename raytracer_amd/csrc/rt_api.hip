@@ -29,6 +29,8 @@ struct rt_context {
     bool mixed = false;             // spheres and rectangles both present
     rt_camera camera{};
     uint32_t image_words[2] = {0, 0};
+    uint32_t lds_words = 0;                 // part of the image each workgroup stages in LDS (same for both images)
+    uint32_t sphere_count = 0, sphere_offset = 0, sphere_tag_offset = 0;
     uint4* d_image[2] = {nullptr, nullptr};
 
     // buffers behind rt_render (host outputs); grow-only
@@ -107,7 +109,10 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     k.output_sum = (p->flags & RT_FLAG_OUTPUT_SUM) ? 1u : 0u;
     out->imode = (int)p->intersect_mode;
     out->rmode = (int)p->rng_mode;
-    k.scene_words = ctx->image_words[out->imode];
+    k.lds_words = ctx->lds_words;
+    k.sphere_count = ctx->sphere_count;
+    k.sphere_offset = ctx->sphere_offset;
+    k.sphere_tag_offset = ctx->sphere_tag_offset;
 
     uint64_t lanes;
     if (p->rng_mode == RT_RNG_ROW_SERIAL) {
@@ -139,7 +144,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     }
     // A CU has 160 KB of LDS and room for 2048 threads: pick the workgroup size so that the LDS
     // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
-    const size_t image_bytes = (size_t)k.scene_words * 4;
+    const size_t image_bytes = (size_t)k.lds_words * 4;
     out->block_threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
     uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
@@ -178,7 +183,7 @@ hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image,
 hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, float* d_radiance,
                   unsigned long long* d_rays, hipStream_t stream) {
     const uint4* image = ctx->d_image[L.imode];
-    size_t lds = (size_t)ctx->image_words[L.imode] * 4;
+    size_t lds = (size_t)ctx->lds_words * 4;
     const bool wide = L.imode == RT_INTERSECT_WIDE8, rows = L.rmode == RT_RNG_ROW_SERIAL;
     if (wide && rows) {
         return ctx->mixed ? launch_variant<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true>(L, lds, image, d_pixels, d_radiance, d_rays, stream)
@@ -349,9 +354,9 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
     size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
     std::vector<uint32_t> images[2] = {rt::pack_scene_image(*w, true), rt::pack_scene_image(*w, false)};
     for (int i = 0; i < 2; ++i)
-        if (images[i].size() * 4 > lds_limit)
-            return fail(ctx, RT_ERR_TOO_LARGE, "scene image is %zu bytes, the LDS of one workgroup holds %zu", images[i].size() * 4,
-                        lds_limit);
+        if ((size_t)images[i][rt::H_LDS_WORDS] * 4 > lds_limit)
+            return fail(ctx, RT_ERR_TOO_LARGE, "planes, rectangles and materials take %zu bytes, the LDS of one workgroup holds %zu",
+                        (size_t)images[i][rt::H_LDS_WORDS] * 4, lds_limit);
     RT_HIP_CHECK(ctx, hipDeviceSynchronize());   // no render may still read the old images
     for (int i = 0; i < 2; ++i) {
         if (ctx->d_image[i]) { RT_HIP_CHECK(ctx, hipFree(ctx->d_image[i])); ctx->d_image[i] = nullptr; }
@@ -360,6 +365,10 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
         ctx->image_words[i] = (uint32_t)images[i].size();
     }
     ctx->camera = *w->camera;
+    ctx->lds_words = images[0][rt::H_LDS_WORDS];
+    ctx->sphere_count = w->sphere_count;
+    ctx->sphere_offset = images[0][rt::H_OFF_SPHERES];
+    ctx->sphere_tag_offset = images[0][rt::H_OFF_SPHERE_TAGS];
     ctx->mixed = w->sphere_count && w->rectangle_count;
     ctx->has_world = true;
     return RT_OK;

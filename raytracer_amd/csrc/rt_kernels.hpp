@@ -37,7 +37,8 @@ struct KernelParams {
     uint32_t lanes_per_pixel, samples_per_lane, batch_offset;  // PIXEL
     uint32_t tile_w, tile_h, tiles_x, tiles_y;          // PIXEL: pixels of one wave
     uint32_t output_sum;
-    uint32_t scene_words;
+    uint32_t lds_words;                                 // leading part of the scene image staged in LDS
+    uint32_t sphere_count, sphere_offset, sphere_tag_offset;   // sphere sections of the global image (words)
     float cam_pos[3], cam_x[3], cam_y[3], film_center[3];
     float half_w, half_h, pixel_w, pixel_h;
 };
@@ -63,19 +64,41 @@ __device__ __forceinline__ float dot_fma(V3 a, V3 b) {
 // division refinement of div2 with numerator 1 (the first quotient estimate is the refined reciprocal
 // itself).  Other arguments (zero, denormal, huge, inf, NaN) take the library forms.  The device
 // self-test compares the two paths over every float of the fast range.
-__device__ __forceinline__ float inv_sqrt_exact(float x) {
-    if (__float_as_uint(x) - 0x0F800000u <= 0x6F800000u - 0x0F800000u) {   // 2^-96 <= x <= 2^96
-        const float s = __builtin_amdgcn_sqrtf(x);
-        const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-        float root = s;
-        if (__builtin_fmaf(-s_dn, s, x) <= 0.0f) root = s_dn;
-        if (__builtin_fmaf(-s_up, s, x) > 0.0f) root = s_up;
-        float y = __builtin_amdgcn_rcpf(root);
-        y = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
-        float q = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
-        return __builtin_fmaf(__builtin_fmaf(-root, q, 1.0f), y, q);
+__device__ __forceinline__ bool in_fast_sqrt_range(float x) {   // 2^-96 <= x <= 2^96
+    return __float_as_uint(x) - 0x0F800000u <= 0x6F800000u - 0x0F800000u;
+}
+// The correctly rounded square root of x in the fast range: the hardware estimate is within one ulp,
+// and the residuals x - (s -+ 1ulp) * s say which neighbour, if any, is the rounded root.
+__device__ __forceinline__ float sqrt_fast_range(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float root = s;
+    if (__builtin_fmaf(-s_dn, s, x) <= 0.0f) root = s_dn;
+    if (__builtin_fmaf(-s_up, s, x) > 0.0f) root = s_up;
+    return root;
+}
+// sqrtf(x), correctly rounded for every argument.  The fast form is evaluated unconditionally (outside
+// its range it yields a value that is thrown away) and the library form replaces it under a branch
+// that no lane of a wave takes in practice, which keeps the common path free of an else-branch.
+__device__ __forceinline__ float sqrt_exact(float x) {
+    float root = sqrt_fast_range(x);
+    if (!in_fast_sqrt_range(x)) {
+        asm volatile("" ::: "memory");   // keep this a branch: the compiler would otherwise evaluate both forms and select
+        root = __builtin_sqrtf(x);
     }
-    return 1.0f / __builtin_sqrtf(x);
+    return root;
+}
+__device__ __forceinline__ float inv_sqrt_exact(float x) {
+    const float root = sqrt_fast_range(x);
+    float y = __builtin_amdgcn_rcpf(root);
+    y = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
+    float q = __builtin_fmaf(__builtin_fmaf(-root, y, 1.0f), y, y);
+    q = __builtin_fmaf(__builtin_fmaf(-root, q, 1.0f), y, q);
+    if (!in_fast_sqrt_range(x)) {
+        asm volatile("" ::: "memory");   // as in sqrt_exact
+        q = 1.0f / __builtin_sqrtf(x);
+    }
+    return q;
 }
 // math_vector.h:167-171: v * (1 / sqrtf(v.v)).
 __device__ __forceinline__ V3 normalize(V3 v) {
@@ -171,8 +194,10 @@ __device__ __forceinline__ uint32_t global_row(const KernelParams& p, uint32_t l
 struct SceneView {
     const float* f;       // LDS image as floats
     const uint32_t* u;    // ... and as words
+    const float4* gspheres;   // sphere records (cx cy cz r*r) in the global image
+    const uint32_t* gtags;    // sphere tags (material | lane << 24) in the global image
     uint32_t n_planes, n_spheres, n_rects;
-    uint32_t off_planes, off_spheres, off_tags, off_rects, off_mats;
+    uint32_t off_planes, off_rects, off_mats;
 };
 
 // World intersection.  best_id: 0 = miss, 1+i plane i, 1+np+k sphere slot k,
@@ -203,6 +228,38 @@ __device__ __forceinline__ void update_closest_rect(float hx, float hy, float t,
         : "vcc");
 }
 
+// The same for a sphere root: if (t > min_hit && t < best_t) { best_t = t; best_id = id; best_lane = lane; }
+// (main.cpp:78-90 / 196-206); best_lane is only kept by the MIXED variant.
+template <bool MIXED>
+__device__ __forceinline__ void update_closest_sphere(float t, float min_hit, uint32_t id, uint32_t lane, float& best_t,
+                                                      uint32_t& best_id, uint32_t& best_lane) {
+    unsigned long long saved_exec;
+    if (MIXED) {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "v_cmpx_lt_f32_e32 %[t], %[best]\n\t"
+            "v_cmpx_lt_f32_e32 %[minhit], %[t]\n\t"
+            "v_mov_b32_e32 %[best], %[t]\n\t"
+            "v_mov_b32_e32 %[bid], %[id]\n\t"
+            "v_mov_b32_e32 %[blane], %[lane]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(saved_exec), [best] "+v"(best_t), [bid] "+v"(best_id), [blane] "+v"(best_lane)
+            : [t] "v"(t), [minhit] "s"(min_hit), [id] "s"(id), [lane] "v"(lane)
+            : "vcc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "v_cmpx_lt_f32_e32 %[t], %[best]\n\t"
+            "v_cmpx_lt_f32_e32 %[minhit], %[t]\n\t"
+            "v_mov_b32_e32 %[best], %[t]\n\t"
+            "v_mov_b32_e32 %[bid], %[id]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(saved_exec), [best] "+v"(best_t), [bid] "+v"(best_id)
+            : [t] "v"(t), [minhit] "s"(min_hit), [id] "s"(id)
+            : "vcc");
+    }
+}
+
 template <int IMODE, bool MIXED>
 __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol) {
     float best_t = 3.402823466e+38f;  // F32Max
@@ -220,7 +277,9 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         }
     }
 
-    // Spheres (main.cpp:60-91 / 182-207).
+    // Spheres (main.cpp:60-91 / 182-207).  The part every sphere pays (b, c, discriminant) is evaluated
+    // for four spheres at a time, so that four independent chains and four LDS reads are in flight; the
+    // roots are only computed, sphere by sphere in slot order, when some lane of the wave needs them.
     if (sv.n_spheres) {
         const float a = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(d, d) : dot(d, d);
         const float denom = 2.0f * a;
@@ -230,10 +289,11 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         float recip = __builtin_amdgcn_rcpf(denom);
         recip = __builtin_fmaf(__builtin_fmaf(-denom, recip, 1.0f), recip, recip);
         const F2 denom2 = splat(denom), recip2 = splat(recip);
-        for (uint32_t k = 0; k < sv.n_spheres; ++k) {
-            const float4 sp = *reinterpret_cast<const float4*>(sv.f + sv.off_spheres + SPHERE_WORDS * k);
+        const uint32_t sphere_base = 1 + sv.n_planes;
+
+        // b, c and the discriminant of one sphere (main.cpp:66-72 / 188-192).
+        auto terms = [&](const float4 sp, float& b, float& c, float& disc) {
             V3 cto = o - mk(sp.x, sp.y, sp.z);
-            float disc, b, c;
             if (IMODE == RT_INTERSECT_WIDE8) {
                 b = 2.0f * dot_fma(d, cto);
                 c = dot_fma(cto, cto) - sp.w;
@@ -243,27 +303,51 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                 c = dot(cto, cto) - sp.w;
                 disc = b * b - four_a * c;
             }
-            // disc > 0: the ray's line meets the sphere.  With b > 0 and c > 0 (centre behind the
-            // origin, origin outside) 4ac > 0, so sqrt(disc) <= sqrt(b*b) = b and both roots are <= 0:
-            // the reference computes them and rejects them against min_hit >= 0; skip them unevaluated.
-            if (disc > 0.0f && !(b > 0.0f && c > 0.0f)) {
-                const float root = __builtin_sqrtf(disc);
-                // (tp, tn) = ((-b + root) / 2a, (-b - root) / 2a), correctly rounded (see div2)
-                const F2 num = f2(-b + root, -b - root);
-                F2 q = num * recip2;
-                F2 r = fma2(-denom2, q, num);
-                q = fma2(r, recip2, q);
-                r = fma2(-denom2, q, num);
-                q = fma2(r, recip2, q);
-                const float tp = q.x, tn = q.y;
-                float t = tp;
-                if (tn > min_hit && tn < tp) t = tn;
-                if (t > min_hit && t < best_t) {
-                    best_t = t;
-                    best_id = 1 + sv.n_planes + k;
-                    if (MIXED) best_lane = sv.u[sv.off_tags + k] >> TAG_LANE_SHIFT;
-                }
+        };
+        // disc > 0: the ray's line meets the sphere.  With b > 0 and c > 0 (centre behind the
+        // origin, origin outside) 4ac > 0, so sqrt(disc) <= sqrt(b*b) = b and both roots are <= 0:
+        // the reference computes them and rejects them against min_hit >= 0; skip them unevaluated.
+        auto roots = [&](uint32_t k, float b, float c, float disc) {
+            if (!(disc > 0.0f) || (b > 0.0f && c > 0.0f)) return;
+            const float root = sqrt_exact(disc);
+            // (tp, tn) = ((-b + root) / 2a, (-b - root) / 2a), correctly rounded (see div2)
+            const F2 num = f2(-b + root, -b - root);
+            F2 q = num * recip2;
+            F2 r = fma2(-denom2, q, num);
+            q = fma2(r, recip2, q);
+            r = fma2(-denom2, q, num);
+            q = fma2(r, recip2, q);
+            // The reference takes the near root tn if (tn > min_hit && tn < tp), else the far root tp.
+            // 2a > 0 and root > 0 give tn <= tp after rounding, and when they are equal either choice
+            // is the same number, so the second condition never decides.
+            const float tp = q.x, tn = q.y;
+            const float t = tn > min_hit ? tn : tp;
+            update_closest_sphere<MIXED>(t, min_hit, sphere_base + k, MIXED ? sv.gtags[k] >> TAG_LANE_SHIFT : 0u,
+                                         best_t, best_id, best_lane);
+        };
+
+        // Groups of four: the records of the next group are requested before the current one is worked on.
+        const uint32_t groups = sv.n_spheres / 4;
+        const float4* rec = sv.gspheres;
+        float4 s0, s1, s2, s3;
+        if (groups) { s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
+        for (uint32_t g = 0; g < groups; ++g) {
+            const float4* next = rec + 4 * (g + 1 < groups ? g + 1 : g);
+            const float4 n0 = next[0], n1 = next[1], n2 = next[2], n3 = next[3];
+            float b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+            terms(s0, b0, c0, d0); terms(s1, b1, c1, d1); terms(s2, b2, c2, d2); terms(s3, b3, c3, d3);
+            if (d0 > 0.0f || d1 > 0.0f || d2 > 0.0f || d3 > 0.0f) {
+                roots(4 * g, b0, c0, d0);
+                roots(4 * g + 1, b1, c1, d1);
+                roots(4 * g + 2, b2, c2, d2);
+                roots(4 * g + 3, b3, c3, d3);
             }
+            s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+        }
+        for (uint32_t k = 4 * groups; k < sv.n_spheres; ++k) {
+            float b, c, disc;
+            terms(rec[k], b, c, disc);
+            roots(k, b, c, disc);
         }
     }
 
@@ -341,7 +425,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
         h.material = sv.u[sv.off_planes + PLANE_WORDS * id + 4];
     } else if (id < sv.n_planes + sv.n_spheres) {
         uint32_t k = id - sv.n_planes;
-        const float4 sp = *reinterpret_cast<const float4*>(sv.f + sv.off_spheres + SPHERE_WORDS * k);
+        const float4 sp = sv.gspheres[k];
         V3 c = mk(sp.x, sp.y, sp.z);
         if (IMODE == RT_INTERSECT_WIDE8) {
             // main.cpp:86-87: FMulAdd(d, t, o) - c, scaled by the reciprocal square root of its
@@ -355,7 +439,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
             V3 hp = o + d * t;                 // main.cpp:203-204
             h.normal = normalize(hp - c);
         }
-        h.material = sv.u[sv.off_tags + k] & TAG_MATERIAL_MASK;
+        h.material = sv.gtags[k] & TAG_MATERIAL_MASK;
     } else {
         uint32_t k = id - sv.n_planes - sv.n_spheres;
         const float4 tail = *reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * (k >> 1) + 24 + 4 * (k & 1));
@@ -419,14 +503,16 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                                                                float* __restrict__ radiance,
                                                                unsigned long long* __restrict__ rays) {
     extern __shared__ uint4 lds_image[];
-    for (uint32_t i = threadIdx.x; i < p.scene_words / 4; i += blockDim.x) lds_image[i] = scene_image[i];
+    for (uint32_t i = threadIdx.x; i < p.lds_words / 4; i += blockDim.x) lds_image[i] = scene_image[i];
     __syncthreads();
 
     SceneView sv;
     sv.f = reinterpret_cast<const float*>(lds_image);
     sv.u = reinterpret_cast<const uint32_t*>(lds_image);
-    sv.n_planes = sv.u[H_NPLANES]; sv.n_spheres = sv.u[H_NSPHERES]; sv.n_rects = sv.u[H_NRECTS];
-    sv.off_planes = sv.u[H_OFF_PLANES]; sv.off_spheres = sv.u[H_OFF_SPHERES]; sv.off_tags = sv.u[H_OFF_SPHERE_TAGS];
+    sv.n_planes = sv.u[H_NPLANES]; sv.n_spheres = p.sphere_count; sv.n_rects = sv.u[H_NRECTS];
+    sv.gspheres = reinterpret_cast<const float4*>(scene_image) + p.sphere_offset / 4;
+    sv.gtags = reinterpret_cast<const uint32_t*>(scene_image) + p.sphere_tag_offset;
+    sv.off_planes = sv.u[H_OFF_PLANES];
     sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
 
     const V3 cam_pos = load3(p.cam_pos), cam_x = load3(p.cam_x), cam_y = load3(p.cam_y);

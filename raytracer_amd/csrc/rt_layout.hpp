@@ -1,13 +1,14 @@
-// Device scene image: the word layout a workgroup copies into LDS, and the host
+// Device scene image: the word layout of the scene in device memory, and the host
 // code that packs it from the caller's AoS arrays (rt_world, include/rt_hip.h).
 //
-// One image per intersection mode, each self-contained (header + sections), so
-// the kernel stages it with a flat 16-byte copy:
+// One image per intersection mode, each self-contained (header + sections).  The first
+// H_LDS_WORDS words (header, planes, rectangles, materials) are staged in LDS by every
+// workgroup with a flat 16-byte copy; the sphere records stay in global memory and are
+// fetched through the scalar cache (every lane of a wave tests the same sphere, so one
+// s_load_dwordx16 brings four of them into scalar registers for all 64 lanes).
 //
 //   header   16 words  counts and section offsets (in words)
 //   planes    8 words  nx ny nz d | material 0 0 0
-//   spheres   4 words  cx cy cz r*r                      (one ds_read_b128 per test)
-//   sph.tag   1 word   material | wide_lane << 24
 //   rects    32 words per PAIR of rectangles (A, B), laid out for packed-FP32 arithmetic:
 //              A.r0x A.r1x A.r0y A.r1y | A.r0z A.r1z A.r0w A.r1w      rows 0,1 of A's inverse transform, interleaved
 //              B.r0x B.r1x B.r0y B.r1y | B.r0z B.r1z B.r0w B.r1w      same for B
@@ -15,6 +16,9 @@
 //              A.nx A.ny A.nz A.tag    | B.nx B.ny B.nz B.tag         tag = material | wide_lane << 24
 //            an odd count is padded with an all-zero rectangle (t = -0/0 = NaN: never hit)
 //   mats     12 words  color[3] ri emit[3] reflection | 1/ri r0 0 0
+//   -------- end of the LDS part --------
+//   spheres   4 words  cx cy cz r*r                      (16-byte aligned)
+//   sph.tag   1 word   material | wide_lane << 24
 //
 // RT_INTERSECT_WIDE8 order: the reference tests primitives 8 at a time, lane j of
 // group g being primitive 8g+j, keeps a running closest hit PER LANE and finally
@@ -35,7 +39,7 @@ namespace rt {
 
 enum : uint32_t {
     H_NPLANES = 0, H_NSPHERES, H_NRECTS, H_NMATS,
-    H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS,
+    H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS, H_LDS_WORDS,
     H_WORDS = 16
 };
 
@@ -58,18 +62,19 @@ inline std::vector<uint32_t> wide_order(uint32_t n) {
 inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
     auto round4 = [](uint32_t v) { return (v + 3u) & ~3u; };
     uint32_t off_planes = H_WORDS;
-    uint32_t off_spheres = off_planes + PLANE_WORDS * w.plane_count;
-    uint32_t off_tags = off_spheres + SPHERE_WORDS * w.sphere_count;
-    uint32_t off_rects = round4(off_tags + w.sphere_count);
+    uint32_t off_rects = off_planes + PLANE_WORDS * w.plane_count;
     const uint32_t rect_slots = (w.rectangle_count + 1u) & ~1u;   // padded to whole pairs
     uint32_t off_mats = off_rects + RECT_PAIR_WORDS * (rect_slots / 2);
-    uint32_t total = round4(off_mats + MAT_WORDS * w.material_count);
+    uint32_t lds_words = round4(off_mats + MAT_WORDS * w.material_count);
+    uint32_t off_spheres = lds_words;
+    uint32_t off_tags = off_spheres + SPHERE_WORDS * w.sphere_count;
+    uint32_t total = round4(off_tags + w.sphere_count);
 
     std::vector<uint32_t> img(total, 0u);
     img[H_NPLANES] = w.plane_count; img[H_NSPHERES] = w.sphere_count;
     img[H_NRECTS] = rect_slots; img[H_NMATS] = w.material_count;
     img[H_OFF_PLANES] = off_planes; img[H_OFF_SPHERES] = off_spheres; img[H_OFF_SPHERE_TAGS] = off_tags;
-    img[H_OFF_RECTS] = off_rects; img[H_OFF_MATS] = off_mats; img[H_TOTAL_WORDS] = total;
+    img[H_OFF_RECTS] = off_rects; img[H_OFF_MATS] = off_mats; img[H_TOTAL_WORDS] = total; img[H_LDS_WORDS] = lds_words;
 
     for (uint32_t i = 0; i < w.plane_count; ++i) {
         const rt_plane& p = w.planes[i];

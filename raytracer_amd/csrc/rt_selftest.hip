@@ -47,8 +47,8 @@ __global__ void div2_kernel(uint64_t seed, uint32_t per_thread, uint32_t exp_lo,
     atomicAdd(&counts[1], 2ull * per_thread);
 }
 
-// Every float whose bit pattern lies in [first, first + count): inv_sqrt_exact against the two library
-// operations it stands for.  NaN results count as equal to each other.
+// Every float whose bit pattern lies in [first, first + count): inv_sqrt_exact and sqrt_exact against the
+// library operations they stand for.  NaN results count as equal to each other.
 __global__ void inv_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* counts, float* first_bad) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long bad = 0;
@@ -56,7 +56,9 @@ __global__ void inv_sqrt_kernel(uint32_t first, uint64_t count, unsigned long lo
         const float x = __uint_as_float(first + (uint32_t)i);
         const float fast = rt::inv_sqrt_exact(x);
         const float slow = 1.0f / __builtin_sqrtf(x);
-        const bool same = __float_as_uint(fast) == __float_as_uint(slow) || (fast != fast && slow != slow);
+        const float root_fast = rt::sqrt_exact(x), root_slow = __builtin_sqrtf(x);
+        const bool same = (__float_as_uint(fast) == __float_as_uint(slow) || (fast != fast && slow != slow)) &&
+                          (__float_as_uint(root_fast) == __float_as_uint(root_slow) || (root_fast != root_fast && root_slow != root_slow));
         if (!same) {
             if (bad == 0 && atomicAdd(&counts[2], 1ull) == 0) { first_bad[0] = x; first_bad[1] = fast; first_bad[2] = slow; }
             ++bad;
@@ -94,7 +96,7 @@ int rt_selftest_div2(uint64_t seed, uint32_t blocks, uint32_t per_thread, uint32
     return (int)e;
 }
 
-// Compares rt::inv_sqrt_exact with 1.0f / sqrtf on the `count` floats whose bit patterns start at
+// Compares rt::inv_sqrt_exact with 1.0f / sqrtf and rt::sqrt_exact with sqrtf on the `count` floats whose bit patterns start at
 // `first_bits` (count = 2^32 from 0 covers every float).  Returns 0 on success; *mismatches receives the
 // number of differing results, first_bad[3] = {x, inv_sqrt_exact, library} of one of them.
 int rt_selftest_inv_sqrt(uint32_t first_bits, uint64_t count, uint64_t* mismatches, float* first_bad) {

@@ -229,6 +229,11 @@ def test_stress_scenes_reduced_size(ctx):
     """The LDS-stress (4096 spheres) and divergence-stress (glass, 32 bounces) scenes at a size the oracle renders in seconds."""
     check_against_oracle(ctx, build_scene("random_spheres", 4096, 1), B.default_params(64, 36, 4))
     check_against_oracle(ctx, build_scene("glass_spheres", 5), B.default_params(64, 36, 16, max_bounces=32))
+    # spheres live in global memory, so their number is not bounded by the LDS: 20000 spheres (400 KB), and
+    # counts that leave 1..3 spheres after the groups of four
+    check_against_oracle(ctx, build_scene("random_spheres", 20000, 1), B.default_params(32, 18, 2))
+    for count in (1, 2, 3, 5, 6, 7):
+        check_against_oracle(ctx, build_scene("random_spheres", count, 3), B.default_params(48, 27, 4))
 
 
 def test_bench_size_cornell_bit_exact(ctx, cornell):
@@ -258,6 +263,7 @@ def test_runs_are_deterministic(ctx, cornell):
 # ---------------------------------------------------------------- error behaviour
 
 def test_errors(ctx, cornell):
+    import copy
     fresh = B.Context(0)
     with pytest.raises(B.RtError) as e:
         fresh.render(B.default_params(8, 8, 1))
@@ -275,12 +281,12 @@ def test_errors(ctx, cornell):
         with pytest.raises(B.RtError) as e:
             ctx.render(p)
         assert e.value.status == 1, fields                      # RT_ERR_INVALID_ARGUMENT
-    big = build_scene("random_spheres", 20000, 1)               # 400 KB of spheres: more than one workgroup's LDS
+    big = copy.deepcopy(cornell)                                # 3600 rectangles = 230 KB: more than one workgroup's LDS
+    big.rectangles = np.tile(cornell.rectangles, 200)
     with pytest.raises(B.RtError) as e:
         ctx.upload_world(big)
     assert e.value.status == 5                                  # RT_ERR_TOO_LARGE
     # non-finite or huge scene values are refused at upload (the kernel's arithmetic forms assume bounded input)
-    import copy
     for field, index, value in (("rectangles", ("inverse_transform", 3, (1, 2)), np.nan), ("rectangles", ("normal", 0, 1), np.inf),
                                 ("materials", ("emit_color", 2, 0), -np.inf), ("camera", ("position", 0, 2), 2e18)):
         broken = copy.deepcopy(cornell)
