@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--lanes-per-pixel", type=int, default=4)
+    ap.add_argument("--lanes-per-pixel", type=int, default=2)
     ap.add_argument("--shard", choices=("samples", "rows"), default="samples")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)

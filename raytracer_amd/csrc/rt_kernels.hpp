@@ -540,10 +540,13 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     } else {
         const uint32_t wave = gid >> 6, lane = gid & 63u;
         const uint32_t q = lane / p.lanes_per_pixel, b = lane % p.lanes_per_pixel;
-        const uint32_t tile_x = wave % p.tiles_x, tile_y = wave / p.tiles_x;
+        // Tile order: column by column, starting with the middle column and moving outwards.
+        const uint32_t column_rank = wave / p.tiles_y, tile_y = wave % p.tiles_y;
+        const uint32_t middle = p.tiles_x / 2u;
+        const uint32_t tile_x = (column_rank & 1u) ? middle - (column_rank + 1u) / 2u : middle + column_rank / 2u;
         x = tile_x * p.tile_w + q % p.tile_w;
         ly = tile_y * p.tile_h + q / p.tile_w;
-        pixel_valid = (tile_y < p.tiles_y) && (x < p.width) && (ly < p.local_rows);
+        pixel_valid = (column_rank < p.tiles_x) && (x < p.width) && (ly < p.local_rows);
         if (pixel_valid) {
             state = pixel_stream_seed(p.seed_constant, x, global_row(p, ly), p.batch_offset + b);
             has_pixel = true;
