@@ -36,7 +36,9 @@ struct rt_context {
     // buffers behind rt_render (host outputs); grow-only
     uint32_t* d_pixels = nullptr;
     float* d_radiance = nullptr;
-    size_t pixel_capacity = 0;
+    size_t pixel_capacity = 0, radiance_capacity = 0;
+    void* h_staging = nullptr;       // pinned host buffer the results are copied through
+    size_t staging_bytes = 0;
     unsigned long long* d_rays = nullptr;
 
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -197,15 +199,76 @@ hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, fl
     return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
 }
 
-// Grow-only device buffers behind the entry points that return results in host memory.
-rt_status ensure_output_capacity(rt_context* ctx, size_t count) {
-    if (count <= ctx->pixel_capacity) return RT_OK;
-    if (ctx->d_pixels) { RT_HIP_CHECK(ctx, hipFree(ctx->d_pixels)); ctx->d_pixels = nullptr; }
-    if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
-    ctx->pixel_capacity = 0;
-    RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pixels, count * sizeof(uint32_t)));
-    RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
-    ctx->pixel_capacity = count;
+// Grow-only device buffers behind the entry points that return results in host memory; each is
+// only allocated once a caller asks for that output (a device allocation costs milliseconds).
+rt_status ensure_output_capacity(rt_context* ctx, size_t count, bool want_pixels, bool want_radiance) {
+    if (want_pixels && count > ctx->pixel_capacity) {
+        if (ctx->d_pixels) { RT_HIP_CHECK(ctx, hipFree(ctx->d_pixels)); ctx->d_pixels = nullptr; }
+        ctx->pixel_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pixels, count * sizeof(uint32_t)));
+        ctx->pixel_capacity = count;
+    }
+    if (want_radiance && count > ctx->radiance_capacity) {
+        if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
+        ctx->radiance_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
+        ctx->radiance_capacity = count;
+    }
+    return RT_OK;
+}
+
+rt_status ensure_staging(rt_context* ctx, size_t bytes) {
+    if (bytes <= ctx->staging_bytes) return RT_OK;
+    if (ctx->h_staging) { RT_HIP_CHECK(ctx, hipHostFree(ctx->h_staging)); ctx->h_staging = nullptr; }
+    ctx->staging_bytes = 0;
+    RT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_staging, bytes, hipHostMallocDefault));
+    ctx->staging_bytes = bytes;
+    return RT_OK;
+}
+
+// Render + copy to host memory.  The device results travel through a pinned staging buffer of the
+// context (a first copy into pageable memory costs the runtime ~8 ms of set-up, and pinned copies run
+// at link speed), then row by row to their place: compact (local row order) for rt_render, or at the
+// row's global position relative to `base_row` in full-size outputs (`scatter`, rt_render_multi).
+rt_status render_to_host(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays,
+                         bool scatter, uint32_t base_row) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L);
+    if (st != RT_OK) return st;
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t width = L.kp.width, rows = L.kp.local_rows, count = rows * width;
+    const size_t pixel_bytes = pixels ? count * sizeof(uint32_t) : 0, radiance_bytes = radiance ? count * 3 * sizeof(float) : 0;
+    st = ensure_output_capacity(ctx, count, pixels != nullptr, radiance != nullptr);
+    if (st != RT_OK) return st;
+    st = ensure_staging(ctx, pixel_bytes + radiance_bytes + 16);
+    if (st != RT_OK) return st;
+    st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, radiance ? ctx->d_radiance : nullptr,
+                          reinterpret_cast<uint64_t*>(ctx->d_rays), nullptr);
+    if (st != RT_OK) return st;
+    char* stage = static_cast<char*>(ctx->h_staging);
+    if (pixels) RT_HIP_CHECK(ctx, hipMemcpyAsync(stage, ctx->d_pixels, pixel_bytes, hipMemcpyDeviceToHost, nullptr));
+    if (radiance) RT_HIP_CHECK(ctx, hipMemcpyAsync(stage + pixel_bytes, ctx->d_radiance, radiance_bytes, hipMemcpyDeviceToHost, nullptr));
+    RT_HIP_CHECK(ctx, hipMemcpyAsync(stage + pixel_bytes + radiance_bytes, ctx->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(nullptr));
+    const uint32_t* staged_pixels = reinterpret_cast<const uint32_t*>(stage);
+    const float* staged_radiance = reinterpret_cast<const float*>(stage + pixel_bytes);
+    if (!scatter) {
+        if (pixels) std::memcpy(pixels, staged_pixels, pixel_bytes);
+        if (radiance) std::memcpy(radiance, staged_radiance, radiance_bytes);
+    } else {
+        for (uint32_t local = 0; local < rows; ++local) {
+            const size_t dst = (size_t)(rt_global_row(params, local) - base_row) * width;
+            if (pixels) std::memcpy(pixels + dst, staged_pixels + (size_t)local * width, width * sizeof(uint32_t));
+            if (radiance) std::memcpy(radiance + dst * 3, staged_radiance + (size_t)local * width * 3, width * 3 * sizeof(float));
+        }
+    }
+    if (rays) {
+        unsigned long long r;
+        std::memcpy(&r, stage + pixel_bytes + radiance_bytes, sizeof r);
+        *rays = r;
+    }
     return RT_OK;
 }
 
@@ -243,6 +306,23 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
     }
+    // One-off runtime set-up belongs to context creation, not to the first render: the first
+    // device-to-host transfer of a process costs the HIP runtime several milliseconds (copy engine
+    // queue, staging), so a 1 MB transfer through the pinned buffer is done here.
+    // Querying a kernel makes the runtime load this library's code object for the device now.
+    constexpr size_t warm_bytes = 1u << 20;
+    void* d_warm = nullptr;
+    hipFuncAttributes attributes;
+    if (hipFuncGetAttributes(&attributes, reinterpret_cast<const void*>(rt::resolve_kernel)) != hipSuccess ||
+        ensure_staging(ctx, warm_bytes) != RT_OK || hipMalloc(&d_warm, warm_bytes) != hipSuccess ||
+        hipMemsetAsync(d_warm, 0, warm_bytes, nullptr) != hipSuccess ||
+        hipMemcpyAsync(ctx->h_staging, d_warm, warm_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
+        if (d_warm) (void)hipFree(d_warm);
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    (void)hipFree(d_warm);
     *out_context = ctx;
     return RT_OK;
 }
@@ -255,6 +335,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->d_pixels) (void)hipFree(ctx->d_pixels);
     if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -394,27 +475,7 @@ rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint
 }
 
 rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays) {
-    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
-    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
-    Launch L;
-    rt_status st = validate_and_plan(ctx, params, &L);
-    if (st != RT_OK) return st;
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    size_t count = (size_t)L.kp.local_rows * L.kp.width;
-    st = ensure_output_capacity(ctx, count);
-    if (st != RT_OK) return st;
-    st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, radiance ? ctx->d_radiance : nullptr,
-                          reinterpret_cast<uint64_t*>(ctx->d_rays), nullptr);
-    if (st != RT_OK) return st;
-    RT_HIP_CHECK(ctx, hipStreamSynchronize(nullptr));
-    if (pixels) RT_HIP_CHECK(ctx, hipMemcpy(pixels, ctx->d_pixels, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (radiance) RT_HIP_CHECK(ctx, hipMemcpy(radiance, ctx->d_radiance, count * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    if (rays) {
-        unsigned long long r = 0;
-        RT_HIP_CHECK(ctx, hipMemcpy(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost));
-        *rays = r;
-    }
-    return RT_OK;
+    return render_to_host(ctx, params, pixels, radiance, rays, false, 0);
 }
 
 rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
@@ -424,10 +485,7 @@ rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, c
         if (!contexts[i]) return RT_ERR_INVALID_ARGUMENT;
     if (params->struct_size != sizeof(rt_render_params) || params->row_end <= params->row_begin || params->width == 0)
         return fail(contexts[0], RT_ERR_INVALID_ARGUMENT, "rt_render_multi: bad struct_size, width or row range");
-    const uint32_t width = params->width;
     std::vector<rt_render_params> shard_params(context_count, *params);
-    std::vector<std::vector<uint32_t>> shard_pixels(context_count);
-    std::vector<std::vector<float>> shard_radiance(context_count);
     std::vector<uint64_t> shard_rays(context_count, 0);
     std::vector<rt_status> status(context_count, RT_OK);
     for (uint32_t i = 0; i < context_count; ++i) {
@@ -435,26 +493,28 @@ rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, c
         p.band_rows = context_count > 1 ? 8u : 0u;
         p.band_index = i;
         p.band_count = context_count;
-        size_t count = (size_t)rt_local_row_count(&p) * width;
-        if (pixels) shard_pixels[i].resize(count);
-        if (radiance) shard_radiance[i].resize(count * 3);
     }
-    // One thread per distinct context; a context listed twice renders its shares back to back.
-    std::vector<std::thread> workers;
-    for (uint32_t i = 0; i < context_count; ++i) {
-        bool first = true;
-        for (uint32_t j = 0; j < i; ++j) first = first && contexts[j] != contexts[i];
-        if (!first) continue;
-        workers.emplace_back([&, i] {
-            for (uint32_t j = i; j < context_count; ++j) {
-                if (contexts[j] != contexts[i]) continue;
-                if (rt_local_row_count(&shard_params[j]) == 0) continue;   // more GPUs than bands
-                status[j] = rt_render(contexts[j], &shard_params[j], pixels ? shard_pixels[j].data() : nullptr,
-                                      radiance ? shard_radiance[j].data() : nullptr, &shard_rays[j]);
-            }
-        });
+    // Each share goes from its GPU's staging buffer straight to its rows of the full-size outputs.
+    auto render_share = [&](uint32_t j) {
+        if (rt_local_row_count(&shard_params[j]) == 0) return;   // more GPUs than bands
+        status[j] = render_to_host(contexts[j], &shard_params[j], pixels, radiance, &shard_rays[j], true, params->row_begin);
+    };
+    if (context_count == 1) {
+        render_share(0);
+    } else {
+        // One thread per distinct context; a context listed twice renders its shares back to back.
+        std::vector<std::thread> workers;
+        for (uint32_t i = 0; i < context_count; ++i) {
+            bool first = true;
+            for (uint32_t j = 0; j < i; ++j) first = first && contexts[j] != contexts[i];
+            if (!first) continue;
+            workers.emplace_back([&, i] {
+                for (uint32_t j = i; j < context_count; ++j)
+                    if (contexts[j] == contexts[i]) render_share(j);
+            });
+        }
+        for (std::thread& t : workers) t.join();
     }
-    for (std::thread& t : workers) t.join();
     uint64_t total = 0;
     for (uint32_t i = 0; i < context_count; ++i) {
         if (status[i] != RT_OK) {
@@ -462,14 +522,6 @@ rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, c
             return status[i];
         }
         total += shard_rays[i];
-        const rt_render_params& p = shard_params[i];
-        const uint32_t rows = rt_local_row_count(&p);
-        for (uint32_t local = 0; local < rows; ++local) {
-            const size_t dst = (size_t)(rt_global_row(&p, local) - params->row_begin) * width;
-            if (pixels) std::memcpy(pixels + dst, shard_pixels[i].data() + (size_t)local * width, (size_t)width * sizeof(uint32_t));
-            if (radiance)
-                std::memcpy(radiance + dst * 3, shard_radiance[i].data() + (size_t)local * width * 3, (size_t)width * 3 * sizeof(float));
-        }
     }
     if (rays) *rays = total;
     return RT_OK;
@@ -494,7 +546,7 @@ rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_
     if (!radiance_sum || pixel_count == 0 || total_samples == 0 || pixel_count > (1ull << 33))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve: bad sum pointer, pixel count or sample count");
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    rt_status st = ensure_output_capacity(ctx, (size_t)pixel_count);
+    rt_status st = ensure_output_capacity(ctx, (size_t)pixel_count, pixels != nullptr, radiance_mean != nullptr);
     if (st != RT_OK) return st;
     float* d_sum = nullptr;
     const size_t sum_bytes = (size_t)pixel_count * 3 * sizeof(float);
