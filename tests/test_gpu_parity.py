@@ -239,7 +239,17 @@ def test_stress_scenes_reduced_size(ctx):
 def test_bench_size_cornell_bit_exact(ctx, cornell):
     """The benchmarked workload itself - Cornell 1920x1080 at 256 spp, PIXEL mode, 1.45e9 rays - is
     bit-identical to the CPU oracle."""
-    check_against_oracle(ctx, cornell, B.default_params(1920, 1080, 256), oracle_mode=O.WIDE8_AVX2)
+    check_against_oracle(ctx, cornell, B.default_params(1920, 1080, 256, lanes_per_pixel=2), oracle_mode=O.WIDE8_AVX2)
+
+
+def test_other_configurations_at_full_resolution(ctx, cornell):
+    """The remaining benchmark configurations at their full image size and bounce cap, with the sample count
+    cut to what the CPU oracle renders in seconds: 4K Cornell, the reference's spheres scene at its shipped
+    720p, the glass lattice with 32 bounces at 1080p, and the 4096-sphere scene at half of 1080p."""
+    check_against_oracle(ctx, cornell, B.default_params(3840, 2160, 32, lanes_per_pixel=2), oracle_mode=O.WIDE8_AVX2)
+    check_against_oracle(ctx, build_scene("spheres"), B.default_params(1280, 720, 128, lanes_per_pixel=2))
+    check_against_oracle(ctx, build_scene("glass_spheres", 5), B.default_params(1920, 1080, 32, lanes_per_pixel=2, max_bounces=32))
+    check_against_oracle(ctx, build_scene("random_spheres", 4096, 1), B.default_params(960, 540, 4, lanes_per_pixel=2))
 
 
 def test_image_statistics_match_the_reference(ctx, cornell, golden_dir):
