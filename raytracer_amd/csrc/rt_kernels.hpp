@@ -260,8 +260,11 @@ __device__ __forceinline__ void update_closest_sphere(float t, float min_hit, ui
     }
 }
 
+// `camera_origin` (wave-uniform): every lane's ray starts at the camera position, so the rectangles'
+// origin transforms are read from the scene image, where the host stored them, instead of computed.
 template <int IMODE, bool MIXED>
-__device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol) {
+__device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
+                                                   bool camera_origin) {
     float best_t = 3.402823466e+38f;  // F32Max
     uint32_t best_id = 0;
     uint32_t best_lane = 0;     // WIDE8 + MIXED: AVX lane of the best hit when it is a sphere
@@ -362,21 +365,28 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
         const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3], z01 = rec[4], z23 = rec[5];
         F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
-        if (IMODE == RT_INTERSECT_WIDE8) {
+        if (camera_origin) {
+            const float4 c01 = rec[8], c2 = rec[9];
+            a_lo = f2(c01.x, c01.y); b_lo = f2(c01.z, c01.w); z_lo = f2(c2.x, c2.y);
+        } else if (IMODE == RT_INTERSECT_WIDE8) {
             // DotProduct(LaneVector4): fma(x,x', fma(y,y', fma(z,z', w*w'))) with w' = 1 for the
-            // origin (w*1 is exact) and w' = 0 for the direction (adds a zero: only the sign of
-            // an exact zero could differ, which no comparison below can see).
+            // origin (w*1 is exact).
             a_lo = fma2(f2(a01.x, a01.y), ox2, fma2(f2(a01.z, a01.w), oy2, fma2(f2(a23.x, a23.y), oz2, f2(a23.z, a23.w))));
             b_lo = fma2(f2(b01.x, b01.y), ox2, fma2(f2(b01.z, b01.w), oy2, fma2(f2(b23.x, b23.y), oz2, f2(b23.z, b23.w))));
             z_lo = fma2(f2(z01.x, z01.y), ox2, fma2(f2(z01.z, z01.w), oy2, fma2(f2(z23.x, z23.y), oz2, f2(z23.z, z23.w))));
-            a_ld = fma2(f2(a01.x, a01.y), dx2, fma2(f2(a01.z, a01.w), dy2, f2(a23.x, a23.y) * dz2));
-            b_ld = fma2(f2(b01.x, b01.y), dx2, fma2(f2(b01.z, b01.w), dy2, f2(b23.x, b23.y) * dz2));
-            z_ld = fma2(f2(z01.x, z01.y), dx2, fma2(f2(z01.z, z01.w), dy2, f2(z23.x, z23.y) * dz2));
         } else {
             // DotProduct(Vector4): x*x' + y*y' + z*z' + w*w', left to right (math_vector.h:341-343).
             a_lo = f2(a01.x, a01.y) * ox2 + f2(a01.z, a01.w) * oy2 + f2(a23.x, a23.y) * oz2 + f2(a23.z, a23.w);
             b_lo = f2(b01.x, b01.y) * ox2 + f2(b01.z, b01.w) * oy2 + f2(b23.x, b23.y) * oz2 + f2(b23.z, b23.w);
             z_lo = f2(z01.x, z01.y) * ox2 + f2(z01.z, z01.w) * oy2 + f2(z23.x, z23.y) * oz2 + f2(z23.z, z23.w);
+        }
+        if (IMODE == RT_INTERSECT_WIDE8) {
+            // w' = 0 for the direction (adds a zero: only the sign of an exact zero could differ,
+            // which no comparison below can see).
+            a_ld = fma2(f2(a01.x, a01.y), dx2, fma2(f2(a01.z, a01.w), dy2, f2(a23.x, a23.y) * dz2));
+            b_ld = fma2(f2(b01.x, b01.y), dx2, fma2(f2(b01.z, b01.w), dy2, f2(b23.x, b23.y) * dz2));
+            z_ld = fma2(f2(z01.x, z01.y), dx2, fma2(f2(z01.z, z01.w), dy2, f2(z23.x, z23.y) * dz2));
+        } else {
             a_ld = f2(a01.x, a01.y) * dx2 + f2(a01.z, a01.w) * dy2 + f2(a23.x, a23.y) * dz2;
             b_ld = f2(b01.x, b01.y) * dx2 + f2(b01.z, b01.w) * dy2 + f2(b23.x, b23.y) * dz2;
             z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
@@ -615,7 +625,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
         if (in_path) {
             rd = normalize(next_dir);
-            const Closest c = intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol);
+            const bool camera_origin = __ballot(bounce != 0) == 0ull;   // all rays of the wave are primary rays
+            const Closest c = intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin);
             ++pixel_rays;
             ++bounce;
             if (c.id != 0) {

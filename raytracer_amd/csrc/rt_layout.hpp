@@ -9,11 +9,14 @@
 //
 //   header   16 words  counts and section offsets (in words)
 //   planes    8 words  nx ny nz d | material 0 0 0
-//   rects    32 words per PAIR of rectangles (A, B), laid out for packed-FP32 arithmetic:
+//   rects    40 words per PAIR of rectangles (A, B), laid out for packed-FP32 arithmetic:
 //              A.r0x A.r1x A.r0y A.r1y | A.r0z A.r1z A.r0w A.r1w      rows 0,1 of A's inverse transform, interleaved
 //              B.r0x B.r1x B.r0y B.r1y | B.r0z B.r1z B.r0w B.r1w      same for B
 //              A.r2x B.r2x A.r2y B.r2y | A.r2z B.r2z A.r2w B.r2w      row 2 of A and of B, interleaved
 //              A.nx A.ny A.nz A.tag    | B.nx B.ny B.nz B.tag         tag = material | wide_lane << 24
+//              A.r0.c A.r1.c B.r0.c B.r1.c | A.r2.c B.r2.c 0 0            rows applied to the CAMERA position c: every
+//                                                                     primary ray starts there, so a wave whose lanes all
+//                                                                     trace primary rays reads these instead of computing them
 //            an odd count is padded with an all-zero rectangle (t = -0/0 = NaN: never hit)
 //   mats     12 words  color[3] ri emit[3] reflection | 1/ri r0 0 0
 //   -------- end of the LDS part --------
@@ -29,6 +32,7 @@
 // (main.cpp:182-239).
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -43,7 +47,7 @@ enum : uint32_t {
     H_WORDS = 16
 };
 
-constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_PAIR_WORDS = 32, MAT_WORDS = 12;
+constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_PAIR_WORDS = 40, MAT_WORDS = 12;
 constexpr uint32_t WIDE_LANES = 8;        // simd.h:17
 constexpr uint32_t TAG_LANE_SHIFT = 24;   // tag = material | lane << 24
 constexpr uint32_t TAG_MATERIAL_MASK = 0x00FFFFFFu;
@@ -105,6 +109,18 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
             rows01[0] = f2u(m[0][col]);
             rows01[1] = f2u(m[1][col]);
             q[16 + 4 * (col / 2) + 2 * (col % 2) + which] = f2u(m[2][col]);
+        }
+        // The camera position through rows 0..2, in the arithmetic of the mode's origin transform
+        // (rt_kernels.hpp, rectangle loop): an fma chain for WIDE8, left-to-right products and sums otherwise.
+        {
+            const float* c = w.camera->position;
+            float rows[3];
+            for (int row = 0; row < 3; ++row)
+                rows[row] = wide ? std::fmaf(m[row][0], c[0], std::fmaf(m[row][1], c[1], std::fmaf(m[row][2], c[2], m[row][3])))
+                                 : m[row][0] * c[0] + m[row][1] * c[1] + m[row][2] * c[2] + m[row][3];
+            q[32 + 2 * which] = f2u(rows[0]);
+            q[33 + 2 * which] = f2u(rows[1]);
+            q[36 + which] = f2u(rows[2]);
         }
         uint32_t* tail = q + 24 + 4 * which;
         tail[0] = f2u(r.normal[0]); tail[1] = f2u(r.normal[1]); tail[2] = f2u(r.normal[2]);
