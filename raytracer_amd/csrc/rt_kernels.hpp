@@ -57,13 +57,10 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ float dot_fma(V3 a, V3 b) {
     return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z));
 }
-// 1.0f / sqrtf(x) with both operations correctly rounded, i.e. exactly what the two library calls
-// give.  For x in [2^-96, 2^96] the compiler's operand scaling, class tests and division fix-up are
-// the identity, and the remaining work is done here without them: the 1-ulp hardware square root is
-// moved to the correctly rounded neighbour by the sign of two residuals, and the reciprocal is the
-// division refinement of div2 with numerator 1 (the first quotient estimate is the refined reciprocal
-// itself).  Other arguments (zero, denormal, huge, inf, NaN) take the library forms.  The device
-// self-test compares the two paths over every float of the fast range.
+// Square root and reciprocal square root without the compiler's operand scaling, class tests and
+// division fix-up.  Those are the identity for x in [2^-96, 2^96]; other arguments (zero, denormal,
+// huge, inf, NaN) take the library forms.  A device self-test compares both functions with the library
+// forms on every float.
 __device__ __forceinline__ bool in_fast_sqrt_range(float x) {   // 2^-96 <= x <= 2^96
     return __float_as_uint(x) - 0x0F800000u <= 0x6F800000u - 0x0F800000u;
 }
@@ -88,6 +85,9 @@ __device__ __forceinline__ float sqrt_exact(float x) {
     }
     return root;
 }
+// 1.0f / sqrtf(x) with both operations correctly rounded, i.e. exactly what the two library calls give:
+// the reciprocal is the division refinement of div2 with numerator 1 (the first quotient estimate is the
+// refined reciprocal itself).
 __device__ __forceinline__ float inv_sqrt_exact(float x) {
     const float root = sqrt_fast_range(x);
     float y = __builtin_amdgcn_rcpf(root);
