@@ -174,12 +174,28 @@ template <int IMODE, int RMODE, bool MIXED>
 hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels, float* d_radiance,
                           unsigned long long* d_rays, hipStream_t stream) {
     auto kernel = rt::render_kernel<IMODE, RMODE, MIXED>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(L.blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
                        d_rays);
     return hipGetLastError();
+}
+
+// Lets every render kernel variant use up to `bytes` of dynamic LDS on the current device.  Done once
+// per context at creation (with the device's maximum), so that a launch is nothing but a launch and can be
+// recorded into a HIP graph.
+hipError_t allow_dynamic_lds(size_t bytes) {
+    const void* kernels[] = {
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true>),
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false>),
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true>),
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false>),
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false>),
+        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>),
+    };
+    for (const void* k : kernels) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, float* d_radiance,
@@ -309,11 +325,11 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
     // One-off runtime set-up belongs to context creation, not to the first render: the first
     // device-to-host transfer of a process costs the HIP runtime several milliseconds (copy engine
     // queue, staging), so a 1 MB transfer through the pinned buffer is done here.
-    // Querying a kernel makes the runtime load this library's code object for the device now.
+    // Setting the kernels' LDS allowance also makes the runtime load this library's code object now.
     constexpr size_t warm_bytes = 1u << 20;
     void* d_warm = nullptr;
-    hipFuncAttributes attributes;
-    if (hipFuncGetAttributes(&attributes, reinterpret_cast<const void*>(rt::resolve_kernel)) != hipSuccess ||
+    const size_t lds_max = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
+    if (allow_dynamic_lds(lds_max) != hipSuccess ||
         ensure_staging(ctx, warm_bytes) != RT_OK || hipMalloc(&d_warm, warm_bytes) != hipSuccess ||
         hipMemsetAsync(d_warm, 0, warm_bytes, nullptr) != hipSuccess ||
         hipMemcpyAsync(ctx->h_staging, d_warm, warm_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
@@ -465,7 +481,10 @@ rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
-    if (rays) RT_HIP_CHECK(ctx, hipMemsetAsync(rays, 0, sizeof(unsigned long long), stream));
+    if (rays) {
+        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
     const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
     if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, stream));
     RT_HIP_CHECK(ctx, launch(ctx, L, d_pixels, d_radiance, rays, stream));

@@ -693,6 +693,10 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     if ((threadIdx.x & 63) == 0 && ray_count != 0 && rays) atomicAdd(rays, ray_count);
 }
 
+// Zeroes the ray counter ahead of a render (a kernel rather than a memset call, so that a recorded
+// HIP graph replays it faithfully).
+__global__ void clear_counter_kernel(unsigned long long* counter) { *counter = 0ull; }
+
 // Tonemap + pack of an accumulated sum (epilogue of main.cpp:393 on its own).
 __global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const float* __restrict__ sum, uint64_t pixel_count,
                                                                 float total_samples, uint32_t* __restrict__ pixels,

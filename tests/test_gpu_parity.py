@@ -320,6 +320,28 @@ def test_kernel_timer(ctx, cornell):
     assert 0 < ms < 1000 and int(rays.item()) > 160 * 90 * 64
 
 
+def test_render_device_can_be_recorded_into_a_graph(ctx, cornell):
+    """rt_render_device allocates nothing and sets no function attributes at launch, so it can be captured
+    into a HIP graph; replays give the pixels and ray count of a direct call."""
+    import torch
+    ctx.upload_world(cornell)
+    dev = torch.device("cuda", 0)
+    p = B.default_params(160, 90, 16, lanes_per_pixel=2)
+    direct = torch.zeros((90, 160), dtype=torch.int32, device=dev)
+    replayed = torch.zeros_like(direct)
+    rays = torch.zeros(2, dtype=torch.int64, device=dev)
+    ctx.render_device(p, direct.data_ptr(), None, rays.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ctx.render_device(p, replayed.data_ptr(), None, rays.data_ptr() + 8, torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(3):
+        replayed.zero_()
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(replayed, direct) and int(rays[1]) == int(rays[0]) > 0
+
+
 def test_packed_division_is_ieee_division():
     """rt::div2 (reciprocal + packed refinement, no operand scaling) against the compiler's IEEE
     division on 2.1e9 random quotients: mantissas uniform, exponents spanning 2^-40 .. 2^40 (the
