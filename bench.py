@@ -39,7 +39,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--lanes-per-pixel", type=int, default=2)
+    ap.add_argument("--lanes-per-pixel", type=int, default=4)
+    ap.add_argument("--no-compact", action="store_true", help="single-launch render (no tail compaction)")
     ap.add_argument("--shard", choices=("samples", "rows"), default="samples")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -103,7 +104,8 @@ def main():
     ctx.upload_world(build_scene("cornell"))
 
     rows_mode = distributed and args.shard == "rows"
-    base = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes)
+    base = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes,
+                            flags=0 if args.no_compact else B.FLAG_COMPACT_TAILS)
     total = args.steps + args.warmup
     rays = torch.zeros(total, dtype=torch.int64, device=device)
     radiance = None
@@ -119,6 +121,7 @@ def main():
         p = base
         pixels = torch.zeros((H, W), dtype=torch.int32, device=device)
 
+    ctx.reserve(p)      # workspace of the compacted render: allocated here, not in a timed step
     stream = torch.cuda.current_stream(device)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
@@ -197,12 +200,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "rng_mode": "pixel", "lanes_per_pixel": B_lanes, "intersect_mode": "wide8",
+                       "compact_tails": not args.no_compact,
                        "max_bounces": 8, "rays_per_step": total_rays // max(args.steps, 1),
                        "device": info.name.decode(), "compute_units": info.compute_units, "clock_mhz": info.clock_khz / 1e3},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flop_per_ray": FLOP_PER_RAY_CORNELL, "kernel_ms": round(kernel_ms, 3),
-                         "kernel": "rt::render_kernel<WIDE8, PIXEL>"},
+                         "kernel": "rt::render_kernel<WIDE8, PIXEL>" if args.no_compact else
+                                   "rt::render_kernel<WIDE8, PIXEL> stage 1 (dominant) + stage 2 + rt::pixel_combine_kernel, timed together"},
         }
         if world_size == 1:
             line["cpu_baseline"] = cpu_baseline(W, H, args.cpu_spp, args.cpu_threads)

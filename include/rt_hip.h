@@ -107,7 +107,13 @@ enum {  /* rt_render_params.intersect_mode */
 
 enum {  /* rt_render_params.flags */
     RT_FLAG_OUTPUT_SUM = 1u,    /* radiance receives the un-normalised sample sum instead of sum/spp */
-    RT_FLAG_TIME_KERNEL = 2u    /* bracket the render kernel with HIP events on its stream (rt_last_kernel_ms) */
+    RT_FLAG_TIME_KERNEL = 2u,   /* bracket the render kernels with HIP events on their stream (rt_last_kernel_ms) */
+    /* RT_RNG_PIXEL only (ignored otherwise, and for very low sample counts): a wave whose lanes have mostly
+     * finished hands its last, nearly complete streams to a second launch that packs them densely; a third
+     * small kernel adds the per-stream sums of each pixel.  Same results bit for bit, fewer idle lanes.  Uses
+     * a workspace owned by the context (16 B per stream + 40 B per lane), allocated by the first render that
+     * needs it or by rt_reserve: that call allocates, later ones do not. */
+    RT_FLAG_COMPACT_TAILS = 4u
 };
 
 typedef struct rt_render_params {
@@ -180,6 +186,10 @@ rt_status rt_render(rt_context* context, const rt_render_params* params,
 rt_status rt_render_device(rt_context* context, const rt_render_params* params,
                            uint32_t* d_pixels, float* d_radiance, uint64_t* d_rays,
                            void* hip_stream);
+
+/* Allocates now whatever device workspace rt_render_device would allocate on its first call with these
+ * parameters (RT_FLAG_COMPACT_TAILS), so that the render calls themselves allocate nothing. */
+rt_status rt_reserve(rt_context* context, const rt_render_params* params);
 
 /* Multi-GPU render into HOST memory: the rows [row_begin,row_end) of `params` are cut into bands of
  * 8 rows, context i renders bands i, i + n, ... concurrently (one host thread per context, the

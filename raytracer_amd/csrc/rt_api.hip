@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <mutex>
@@ -38,6 +39,9 @@ struct rt_context {
     float* d_radiance = nullptr;
     size_t pixel_capacity = 0, radiance_capacity = 0;
     void* h_staging = nullptr;       // pinned host buffer the results are copied through
+    // workspace of RT_FLAG_COMPACT_TAILS renders; grow-only
+    rt::Workspace ws{nullptr, nullptr, nullptr};
+    size_t lane_sum_capacity = 0, pool_entry_capacity = 0;
     size_t staging_bytes = 0;
     unsigned long long* d_rays = nullptr;
 
@@ -67,10 +71,25 @@ rt_status fail(rt_context* ctx, rt_status st, const char* fmt, ...) {
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
+// Tail compaction (see render_kernel): a stage-1 wave stops when at most `pool_threshold()` of its 64 lanes
+// still have work and none of them has more than `pool_max_samples()` samples left to start.  The second
+// bound keeps the handed-over streams short: stage 2 only begins when stage 1 has ended, so a long stream
+// would run there on its own (measured on the Cornell bench without it: stage 1 -1.1 ms, stage 2 +1.6 ms).
+// Defaults from a sweep on the bench (T 16..48 x S 2..32); the environment variables are for experiments.
+uint32_t env_or(const char* name, long fallback, long lo, long hi) {
+    const char* env = std::getenv(name);
+    long v = env ? std::strtol(env, nullptr, 10) : fallback;
+    return (uint32_t)(v < lo ? lo : v > hi ? hi : v);
+}
+uint32_t pool_threshold() { static const uint32_t v = env_or("RT_POOL_THRESHOLD", 32, 1, 63); return v; }
+uint32_t pool_max_samples() { static const uint32_t v = env_or("RT_POOL_MAX_SAMPLES", 8, 0, 1 << 20); return v; }
+
 struct Launch {
     rt::KernelParams kp;
     uint32_t blocks, block_threads;
     int imode, rmode;
+    bool compact = false;            // RT_FLAG_COMPACT_TAILS on per-pixel streams: stages 1 + 2 + combine
+    uint32_t stage2_blocks = 0;
 };
 
 rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out) {
@@ -143,6 +162,8 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         k.tiles_y = (k.local_rows + k.tile_h - 1) / k.tile_h;
         k.rows_per_order = 1; k.order_count = 0;
         lanes = (uint64_t)k.tiles_x * k.tiles_y * 64;
+        // worth it only when a lane's samples are many compared with what may be handed over
+        out->compact = (p->flags & RT_FLAG_COMPACT_TAILS) != 0 && k.samples_per_lane >= 4 * (pool_max_samples() + 1);
     }
     // A CU has 160 KB of LDS and room for 2048 threads: pick the workgroup size so that the LDS
     // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
@@ -151,6 +172,18 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
     out->blocks = (uint32_t)blocks;
+    if (out->compact) {
+        // A stage-1 wave hands over at most pool_threshold streams, so waves * threshold entries always suffice.
+        k.pool_threshold = pool_threshold();
+        k.pool_max_samples = pool_max_samples();
+        const uint64_t capacity = blocks * (out->block_threads / 64u) * k.pool_threshold;
+        if (capacity > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "image too large for RT_FLAG_COMPACT_TAILS");
+        k.pool_capacity = (uint32_t)capacity;
+        // Stage 2 runs persistent waves that fetch streams until the pool is empty: four waves per SIMD.
+        const uint64_t stage2_waves = (uint64_t)ctx->props.multiProcessorCount * 16u;
+        const uint64_t stage2_blocks = (stage2_waves * 64u + out->block_threads - 1) / out->block_threads;
+        out->stage2_blocks = (uint32_t)(stage2_blocks < blocks ? stage2_blocks : blocks);
+    }
 
     // Film constants (main.cpp:350-368), rounded operation by operation.
     const rt_camera& c = ctx->camera;
@@ -170,49 +203,49 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     return RT_OK;
 }
 
-template <int IMODE, int RMODE, bool MIXED>
+template <int IMODE, int RMODE, bool MIXED, int STAGE>
 hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels, float* d_radiance,
-                          unsigned long long* d_rays, hipStream_t stream) {
-    auto kernel = rt::render_kernel<IMODE, RMODE, MIXED>;
-    hipLaunchKernelGGL(kernel, dim3(L.blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
-                       d_rays);
+                          unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
+    auto kernel = rt::render_kernel<IMODE, RMODE, MIXED, STAGE>;
+    const uint32_t blocks = STAGE == 2 ? L.stage2_blocks : L.blocks;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
+                       d_rays, ws);
     return hipGetLastError();
 }
+
+// Every instantiation of the render kernel: (intersect mode, stream layout, mixed scene, stage).  Stages 1
+// and 2 exist for the per-pixel stream layout only.
+#define RT_FOR_EACH_KERNEL(X)                                                                   \
+    X(RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true, 0) X(RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false, 0) \
+    X(RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false, 0)                                         \
+    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 0) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 0) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 0) \
+    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 1) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 1) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 1) \
+    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 2) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 2) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 2)
 
 // Lets every render kernel variant use up to `bytes` of dynamic LDS on the current device.  Done once
 // per context at creation (with the device's maximum), so that a launch is nothing but a launch and can be
 // recorded into a HIP graph.
 hipError_t allow_dynamic_lds(size_t bytes) {
-    const void* kernels[] = {
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true>),
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false>),
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true>),
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false>),
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false>),
-        reinterpret_cast<const void*>(rt::render_kernel<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>),
-    };
-    for (const void* k : kernels) {
-        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-    }
+#define RT_ALLOW(IM, RM, MX, ST)                                                                                             \
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rt::render_kernel<IM, RM, MX, ST>),                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); e != hipSuccess)         \
+        return e;
+    RT_FOR_EACH_KERNEL(RT_ALLOW)
+#undef RT_ALLOW
     return hipSuccess;
 }
 
-hipError_t launch(const rt_context* ctx, const Launch& L, uint32_t* d_pixels, float* d_radiance,
-                  unsigned long long* d_rays, hipStream_t stream) {
+hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d_pixels, float* d_radiance,
+                  unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
     const uint4* image = ctx->d_image[L.imode];
-    size_t lds = (size_t)ctx->lds_words * 4;
-    const bool wide = L.imode == RT_INTERSECT_WIDE8, rows = L.rmode == RT_RNG_ROW_SERIAL;
-    if (wide && rows) {
-        return ctx->mixed ? launch_variant<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true>(L, lds, image, d_pixels, d_radiance, d_rays, stream)
-                          : launch_variant<RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
-    } else if (wide) {
-        return ctx->mixed ? launch_variant<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true>(L, lds, image, d_pixels, d_radiance, d_rays, stream)
-                          : launch_variant<RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
-    } else if (rows) {
-        return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
-    }
-    return launch_variant<RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false>(L, lds, image, d_pixels, d_radiance, d_rays, stream);
+    const size_t lds = (size_t)ctx->lds_words * 4;
+    const bool mixed = L.imode == RT_INTERSECT_WIDE8 && ctx->mixed;
+#define RT_DISPATCH(IM, RM, MX, ST)                                                  \
+    if (L.imode == IM && L.rmode == RM && mixed == MX && stage == ST)                \
+        return launch_variant<IM, RM, MX, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);
+    RT_FOR_EACH_KERNEL(RT_DISPATCH)
+#undef RT_DISPATCH
+    return hipErrorInvalidValue;
 }
 
 // Grow-only device buffers behind the entry points that return results in host memory; each is
@@ -229,6 +262,24 @@ rt_status ensure_output_capacity(rt_context* ctx, size_t count, bool want_pixels
         ctx->radiance_capacity = 0;
         RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
         ctx->radiance_capacity = count;
+    }
+    return RT_OK;
+}
+
+rt_status ensure_workspace(rt_context* ctx, const Launch& L) {
+    const size_t streams = (size_t)L.kp.local_rows * L.kp.width * L.kp.lanes_per_pixel;
+    if (!ctx->ws.pool_count) RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.pool_count, sizeof(uint32_t)));
+    if (streams > ctx->lane_sum_capacity) {
+        if (ctx->ws.lane_sums) { RT_HIP_CHECK(ctx, hipFree(ctx->ws.lane_sums)); ctx->ws.lane_sums = nullptr; }
+        ctx->lane_sum_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.lane_sums, streams * sizeof(float4)));
+        ctx->lane_sum_capacity = streams;
+    }
+    if (L.kp.pool_capacity > ctx->pool_entry_capacity) {
+        if (ctx->ws.pool) { RT_HIP_CHECK(ctx, hipFree(ctx->ws.pool)); ctx->ws.pool = nullptr; }
+        ctx->pool_entry_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.pool, (size_t)L.kp.pool_capacity * rt::POOL_VEC4 * sizeof(uint4)));
+        ctx->pool_entry_capacity = L.kp.pool_capacity;
     }
     return RT_OK;
 }
@@ -352,6 +403,9 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
+    if (ctx->ws.lane_sums) (void)hipFree(ctx->ws.lane_sums);
+    if (ctx->ws.pool) (void)hipFree(ctx->ws.pool);
+    if (ctx->ws.pool_count) (void)hipFree(ctx->ws.pool_count);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -481,16 +535,39 @@ rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
-    if (rays) {
-        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays);
+    if (L.compact) {
+        st = ensure_workspace(ctx, L);   // allocates only when this render needs more than any before it
+        if (st != RT_OK) return st;
+    }
+    if (rays || L.compact) {
+        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays, L.compact ? ctx->ws.pool_count : nullptr);
         RT_HIP_CHECK(ctx, hipGetLastError());
     }
     const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
     if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, stream));
-    RT_HIP_CHECK(ctx, launch(ctx, L, d_pixels, d_radiance, rays, stream));
+    if (!L.compact) {
+        RT_HIP_CHECK(ctx, launch(ctx, L, 0, d_pixels, d_radiance, rays, ctx->ws, stream));
+    } else {
+        RT_HIP_CHECK(ctx, launch(ctx, L, 1, d_pixels, d_radiance, rays, ctx->ws, stream));
+        RT_HIP_CHECK(ctx, launch(ctx, L, 2, d_pixels, d_radiance, rays, ctx->ws, stream));
+        const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
+        hipLaunchKernelGGL(rt::pixel_combine_kernel, dim3((uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS)),
+                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ctx->ws.lane_sums, d_pixels, d_radiance);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
     if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));
     ctx->timed = timed;
     return RT_OK;
+}
+
+rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L);
+    if (st != RT_OK) return st;
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return L.compact ? ensure_workspace(ctx, L) : RT_OK;
 }
 
 rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays) {

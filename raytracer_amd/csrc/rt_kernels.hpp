@@ -37,11 +37,20 @@ struct KernelParams {
     uint32_t lanes_per_pixel, samples_per_lane, batch_offset;  // PIXEL
     uint32_t tile_w, tile_h, tiles_x, tiles_y;          // PIXEL: pixels of one wave
     uint32_t output_sum;
+    uint32_t pool_threshold, pool_max_samples, pool_capacity;             // tail compaction (STAGE 1 and 2), see render_kernel
     uint32_t lds_words;                                 // leading part of the scene image staged in LDS
     uint32_t sphere_count, sphere_offset, sphere_tag_offset;   // sphere sections of the global image (words)
     float cam_pos[3], cam_x[3], cam_y[3], film_center[3];
     float half_w, half_h, pixel_w, pixel_h;
 };
+
+// Device workspace of the tail compaction: per-stream sums, the pool of unfinished streams and its fill count.
+struct Workspace {
+    float4* lane_sums;        // [pixel * lanes_per_pixel + batch]: finished sum of that stream (xyz)
+    uint4* pool;              // POOL_VEC4 x uint4 per deposited stream
+    uint32_t* pool_count;     // streams deposited by STAGE 1
+};
+constexpr uint32_t POOL_VEC4 = 5;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
 
 struct V3 { float x, y, z; };
 
@@ -507,11 +516,22 @@ __device__ __forceinline__ void emit_pixel(const KernelParams& p, V3 sum, size_t
 constexpr int MAX_BLOCK_THREADS = 1024;
 constexpr int BLOCK_THREADS = 256;   // resolve_kernel
 
-template <int IMODE, int RMODE, bool MIXED>
+// STAGE 0: the whole render in one launch (each wave finishes its streams and writes its pixels).
+// STAGE 1 and 2 (PIXEL streams only) split it to compact the tails of the waves: towards the end of a wave
+// most lanes have finished their samples and idle while a few streams go on.  A STAGE 1 wave therefore
+// stops once at most `pool_threshold` lanes still have work and each of them has at most `pool_max_samples`
+// samples left to start: finished lanes store their stream's sum in `lane_sums`, unfinished ones deposit
+// their complete state (stream, sample count, partial sum, pending ray) in the pool.  STAGE 2 runs
+// persistent waves whose lanes take deposited streams from the pool, one after another, and run them to
+// the end with the same loop.  pixel_combine_kernel then adds the lanes_per_pixel sums of every pixel in
+// the order of the STAGE 0 tree and writes the pixel.  A stream is computed by the same operations in the
+// same order wherever it runs, so the results are those of STAGE 0 bit for bit.
+template <int IMODE, int RMODE, bool MIXED, int STAGE>
 __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
                                                                uint32_t* __restrict__ pixels,
                                                                float* __restrict__ radiance,
-                                                               unsigned long long* __restrict__ rays) {
+                                                               unsigned long long* __restrict__ rays,
+                                                               Workspace ws) {
     extern __shared__ uint4 lds_image[];
     for (uint32_t i = threadIdx.x; i < p.lds_words / 4; i += blockDim.x) lds_image[i] = scene_image[i];
     __syncthreads();
@@ -534,6 +554,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     uint32_t state = 1;
     uint32_t x = 0, ly = 0, ly_end = 0;   // current pixel (local row) and end of the lane's rows
     uint32_t samples_left = 0;            // samples still to START in the current pixel
+    uint32_t sid = 0;                     // PIXEL: index of the lane's stream, pixel * lanes_per_pixel + batch
     bool has_pixel = false;               // the lane still owns an unfinished pixel
     bool pixel_valid = false;             // PIXEL: lane maps to a pixel inside the image
 
@@ -547,6 +568,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             has_pixel = true;
             samples_left = p.spp;
         }
+    } else if (STAGE == 2) {
+        // the stream comes from the pool: restored after the common initialisation below
     } else {
         const uint32_t wave = gid >> 6, lane = gid & 63u;
         const uint32_t q = lane / p.lanes_per_pixel, b = lane % p.lanes_per_pixel;
@@ -561,9 +584,11 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             state = pixel_stream_seed(p.seed_constant, x, global_row(p, ly), p.batch_offset + b);
             has_pixel = true;
             samples_left = p.samples_per_lane;
+            sid = (ly * p.width + x) * p.lanes_per_pixel + b;
         }
     }
-
+    // STAGE 2: persistent waves; every lane fetches deposited streams from the pool until it is empty.
+    const uint32_t pool_count = STAGE == 2 ? min(ws.pool_count[0], p.pool_capacity) : 0u;
     float film_x = 0.0f, film_y = 0.0f;
     if (has_pixel) {
         film_y = ((float)(int32_t)global_row(p, ly) / (float)(int32_t)p.height) * -2.0f + 1.0f;   // main.cpp:375
@@ -578,8 +603,20 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     bool need_sample = has_pixel;         // the lane's previous path ended (or it has not started one)
     unsigned long long ray_count = 0;
     uint32_t pixel_rays = 0;
+    if (STAGE == 2) need_sample = true;   // every lane starts by fetching a stream
 
+    // STAGE 2: the pool is dealt to the waves in groups of 64 entries, group g to wave g mod (number of
+    // waves); a wave walks through its entries with a cursor that all its lanes advance together.
+    uint32_t wave_cursor = 0;
     while (true) {
+        uint32_t fetch_slot = 0xFFFFFFFFu;
+        if (STAGE == 2) {
+            const unsigned long long asking = __ballot(need_sample && samples_left == 0);
+            const uint32_t mine = wave_cursor + (uint32_t)__builtin_popcountll(asking & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+            fetch_slot = ((gid >> 6) + (mine >> 6) * waves) * 64u + (mine & 63u);
+            wave_cursor += (uint32_t)__builtin_popcountll(asking);
+        }
         // ---- lanes between paths: close the pixel if it is complete, start the next sample
         //      (main.cpp:379-388).  Only the un-normalised primary direction is formed here; the
         //      normalisation below is shared with the lanes that continue a path.
@@ -603,11 +640,32 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                     } else {
                         has_pixel = false;
                     }
+                } else if (STAGE == 2) {
+                    // The lane's stream is complete: store its sum, then take the next deposited stream.
+                    if (has_pixel) ws.lane_sums[sid] = make_float4(pixel_sum.x, pixel_sum.y, pixel_sum.z, 0.0f);
+                    has_pixel = false;
+                    const uint32_t slot = fetch_slot;
+                    if (slot < pool_count) {
+                        const uint4* e = ws.pool + (size_t)slot * POOL_VEC4;
+                        const uint4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+                        sid = e0.x; state = e0.y; samples_left = e0.z; bounce = e0.w;
+                        pixel_sum = mk(__uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z));
+                        ro = mk(__uint_as_float(e1.w), __uint_as_float(e2.x), __uint_as_float(e2.y));
+                        next_dir = mk(__uint_as_float(e2.z), __uint_as_float(e2.w), __uint_as_float(e3.x));
+                        attenuation = mk(__uint_as_float(e3.y), __uint_as_float(e3.z), __uint_as_float(e3.w));
+                        result = mk(__uint_as_float(e4.x), __uint_as_float(e4.y), __uint_as_float(e4.z));
+                        const uint32_t pixel = sid / p.lanes_per_pixel;
+                        x = pixel % p.width; ly = pixel / p.width;
+                        film_y = ((float)(int32_t)global_row(p, ly) / (float)(int32_t)p.height) * -2.0f + 1.0f;
+                        film_x = (((float)(int32_t)x / (float)(int32_t)p.width) * 2.0f - 1.0f);
+                        in_path = true;     // the deposited stream continues with its pending ray
+                    }
                 } else {
                     has_pixel = false;   // the pixel is written after the loop (cross-lane sum)
                 }
             }
-            if (has_pixel) {
+            if (STAGE == 2 && in_path) has_pixel = true;   // fetched: no new sample in this iteration
+            else if (has_pixel) {
                 --samples_left;
                 float off_x = film_x + random_bilateral(state) * p.pixel_w;
                 float off_y = film_y + random_bilateral(state) * p.pixel_h;
@@ -620,7 +678,11 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 in_path = true;
             }
         }
-        if (__ballot(in_path) == 0ull) break;   // no lane of the wave has a ray left
+        const unsigned long long active = __ballot(in_path);
+        if (active == 0ull) break;   // no lane of the wave has a ray left
+        if (STAGE == 1 && (uint32_t)__builtin_popcountll(active) <= p.pool_threshold &&
+            __ballot(in_path && samples_left > p.pool_max_samples) == 0ull)
+            break;   // hand the tail over: few lanes left, each with little left to do
 
         // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
         if (in_path) {
@@ -677,7 +739,30 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
 
     // ---- epilogue ------------------------------------------------------------------
     ray_count += pixel_rays;
-    if (RMODE == RT_RNG_PIXEL) {
+    if (RMODE == RT_RNG_PIXEL && STAGE != 0) {
+        // Finished streams leave their sum, unfinished ones (STAGE 1 only) their state.
+        const unsigned long long unfinished = __ballot(in_path);
+        uint32_t base = 0;
+        if (unfinished) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(unfinished);
+            if ((threadIdx.x & 63u) == leader) base = atomicAdd(ws.pool_count, (uint32_t)__builtin_popcountll(unfinished));
+            base = __shfl(base, leader);
+        }
+        if (in_path) {
+            const uint32_t slot = base + (uint32_t)__builtin_popcountll(unfinished & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            if (slot < p.pool_capacity) {   // always true: capacity = waves * pool_threshold
+                uint4* e = ws.pool + (size_t)slot * POOL_VEC4;
+                e[0] = make_uint4(sid, state, samples_left, bounce);
+                e[1] = make_uint4(__float_as_uint(pixel_sum.x), __float_as_uint(pixel_sum.y), __float_as_uint(pixel_sum.z), __float_as_uint(ro.x));
+                e[2] = make_uint4(__float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(next_dir.x), __float_as_uint(next_dir.y));
+                e[3] = make_uint4(__float_as_uint(next_dir.z), __float_as_uint(attenuation.x), __float_as_uint(attenuation.y), __float_as_uint(attenuation.z));
+                e[4] = make_uint4(__float_as_uint(result.x), __float_as_uint(result.y), __float_as_uint(result.z), 0u);
+            }
+        } else if (STAGE == 1 && pixel_valid) {
+            ws.lane_sums[sid] = make_float4(pixel_sum.x, pixel_sum.y, pixel_sum.z, 0.0f);
+        }
+    }
+    if (RMODE == RT_RNG_PIXEL && STAGE == 0) {
         // Pairwise tree over the lanes_per_pixel partial sums of each pixel.
         for (uint32_t stride = 1; stride < p.lanes_per_pixel; stride <<= 1) {
             float sx = __shfl_down(pixel_sum.x, stride);
@@ -693,9 +778,32 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     if ((threadIdx.x & 63) == 0 && ray_count != 0 && rays) atomicAdd(rays, ray_count);
 }
 
-// Zeroes the ray counter ahead of a render (a kernel rather than a memset call, so that a recorded
-// HIP graph replays it faithfully).
-__global__ void clear_counter_kernel(unsigned long long* counter) { *counter = 0ull; }
+// Zeroes the ray counter (and the pool fill count) ahead of a render: a kernel rather than a memset
+// call, so that a recorded HIP graph replays it faithfully.
+__global__ void clear_counter_kernel(unsigned long long* counter, uint32_t* pool_count) {
+    if (counter) *counter = 0ull;
+    if (pool_count) *pool_count = 0u;
+}
+
+// Last step of the compacted render: the pixel is the pairwise tree over its lanes_per_pixel stream sums,
+// in the order of the in-wave tree of STAGE 0 (halves added left + right), then color / sampleSize and pack.
+__device__ inline V3 tree_sum(const float4* sums, uint32_t n) {   // n: power of two <= 64
+    V3 partial[7];   // partial[l]: sum of a completed left block of 2^l streams waiting for its right neighbour
+    V3 v = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        v = mk(sums[i].x, sums[i].y, sums[i].z);
+        uint32_t level = 0;
+        for (; (i >> level) & 1u; ++level) v = partial[level] + v;
+        partial[level] = v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(BLOCK_THREADS) void pixel_combine_kernel(KernelParams p, const float4* __restrict__ lane_sums,
+                                                                      uint32_t* __restrict__ pixels, float* __restrict__ radiance) {
+    const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    if (i >= (size_t)p.local_rows * p.width) return;
+    emit_pixel(p, tree_sum(lane_sums + i * p.lanes_per_pixel, p.lanes_per_pixel), i, pixels, radiance);
+}
 
 // Tonemap + pack of an accumulated sum (epilogue of main.cpp:393 on its own).
 __global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const float* __restrict__ sum, uint64_t pixel_count,

@@ -27,6 +27,7 @@ struct Options {
     unsigned seed_constant = 262346;         // main.cpp:370
     std::string rng = "pixel";
     unsigned lanes_per_pixel = 1;
+    bool compact = false;                    // RT_FLAG_COMPACT_TAILS
     std::string intersect = "wide";
     unsigned count = 0;
     unsigned long long scene_seed = 1;
@@ -44,7 +45,7 @@ void Usage() {
     std::fprintf(stderr,
                  "usage: raytracer [--scene cornell|spheres|random_spheres|glass_spheres|FILE.rtsc] [--count N] [--scene-seed S]\n"
                  "                 [--width W] [--height H] [--spp N] [--bounces N] [--seed-constant N]\n"
-                 "                 [--rng pixel|row] [--lanes-per-pixel N] [--intersect wide|scalar]\n"
+                 "                 [--rng pixel|row] [--lanes-per-pixel N] [--compact] [--intersect wide|scalar]\n"
                  "                 [--gpus N | --devices 0,1,...] [--out FILE.bmp]\n"
                  "                 [--passes N] [--checkpoint FILE.rtfb] [--resume FILE.rtfb]\n");
 }
@@ -55,6 +56,7 @@ bool Parse(int argc, char** argv, Options* o) {
         auto value = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
         const char* v = nullptr;
         if (a == "--help" || a == "-h") return false;
+        if (a == "--compact") { o->compact = true; continue; }
         if (!(v = value())) return false;
         if (a == "--scene") o->scene = v;
         else if (a == "--count") o->count = (unsigned)std::strtoul(v, nullptr, 0);
@@ -122,6 +124,7 @@ int main(int argc, char** argv) {
     params.seed_constant = opt.seed_constant;
     params.rng_mode = opt.rng == "row" ? RT_RNG_ROW_SERIAL : RT_RNG_PIXEL;
     params.lanes_per_pixel = opt.lanes_per_pixel;
+    if (opt.compact) params.flags |= RT_FLAG_COMPACT_TAILS;
     params.intersect_mode = opt.intersect == "scalar" ? RT_INTERSECT_SCALAR : RT_INTERSECT_WIDE8;
 
     // The render: interleaved 8-row bands, one host thread per GPU, assembled in image.pixelData.

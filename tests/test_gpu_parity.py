@@ -320,13 +320,49 @@ def test_kernel_timer(ctx, cornell):
     assert 0 < ms < 1000 and int(rays.item()) > 160 * 90 * 64
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4, 16])
+def test_tail_compaction_changes_nothing_but_the_schedule(ctx, cornell, spheres, lanes):
+    """RT_FLAG_COMPACT_TAILS (stage 1 + pool + stage 2 + per-pixel combine) gives the pixels, radiance and ray
+    count of the single-launch render, bit for bit: rectangles, spheres + plane, glass with 32 bounces, ragged
+    sizes, row bands, sum output."""
+    cases = [(cornell, B.default_params(333, 77, 64 * lanes, lanes_per_pixel=lanes)),
+             (spheres, B.default_params(160, 90, 48 * lanes, lanes_per_pixel=lanes, intersect_mode=B.INTERSECT_SCALAR)),
+             (build_scene("glass_spheres", 3), B.default_params(96, 54, 64 * lanes, lanes_per_pixel=lanes, max_bounces=32)),
+             (cornell, B.default_params(200, 120, 40 * lanes, lanes_per_pixel=lanes, band_rows=8, band_index=1, band_count=3,
+                                        flags=B.FLAG_OUTPUT_SUM, batch_offset=5)),
+             (cornell, B.default_params(64, 36, 4 * lanes, lanes_per_pixel=lanes))]     # too few samples: falls back to one launch
+    for scene, p in cases:
+        ctx.upload_world(scene)
+        plain = ctx.render(p)
+        p.flags |= B.FLAG_COMPACT_TAILS
+        ctx.reserve(p)
+        compact = ctx.render(p)
+        assert compact[2] == plain[2]
+        assert np.array_equal(compact[0], plain[0]) and np.array_equal(bits(compact[1]), bits(plain[1]))
+    # ROW_SERIAL ignores the flag
+    ctx.upload_world(cornell)
+    p = B.default_params(64, 36, 16, rng_mode=B.RNG_ROW_SERIAL)
+    plain = ctx.render(p)
+    p.flags = B.FLAG_COMPACT_TAILS
+    assert np.array_equal(ctx.render(p)[0], plain[0])
+
+
+def test_compacted_bench_workload_bit_exact(ctx, cornell):
+    """The benchmarked launch sequence (Cornell 1920x1080 at 256 spp, 4 lanes per pixel, compacted tails)
+    against the CPU oracle."""
+    check_against_oracle(ctx, cornell, B.default_params(1920, 1080, 256, lanes_per_pixel=4, flags=B.FLAG_COMPACT_TAILS),
+                         oracle_mode=O.WIDE8_AVX2)
+
+
 def test_render_device_can_be_recorded_into_a_graph(ctx, cornell):
-    """rt_render_device allocates nothing and sets no function attributes at launch, so it can be captured
-    into a HIP graph; replays give the pixels and ray count of a direct call."""
+    """rt_render_device allocates nothing (after rt_reserve) and sets no function attributes at launch, so
+    it can be captured into a HIP graph - here the four kernels of a compacted render; replays give the
+    pixels and ray count of a direct call."""
     import torch
     ctx.upload_world(cornell)
     dev = torch.device("cuda", 0)
-    p = B.default_params(160, 90, 16, lanes_per_pixel=2)
+    p = B.default_params(160, 90, 128, lanes_per_pixel=2, flags=B.FLAG_COMPACT_TAILS)
+    ctx.reserve(p)                      # the workspace is allocated here, not inside the capture
     direct = torch.zeros((90, 160), dtype=torch.int32, device=dev)
     replayed = torch.zeros_like(direct)
     rays = torch.zeros(2, dtype=torch.int64, device=dev)
