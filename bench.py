@@ -177,7 +177,8 @@ def main():
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"cornell_{W}x{H}_{spp}spp")
+                key = f"cornell_{W}x{H}_{spp}spp" + ("_single_launch" if args.no_compact else "")
+                traffic = json.loads(tfile.read_text()).get(key)
             except (ValueError, OSError):
                 traffic = None
         if rows_mode:

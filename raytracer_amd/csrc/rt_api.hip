@@ -40,8 +40,8 @@ struct rt_context {
     size_t pixel_capacity = 0, radiance_capacity = 0;
     void* h_staging = nullptr;       // pinned host buffer the results are copied through
     // workspace of RT_FLAG_COMPACT_TAILS renders; grow-only
-    rt::Workspace ws{nullptr, nullptr, nullptr};
-    size_t lane_sum_capacity = 0, pool_entry_capacity = 0;
+    rt::Workspace ws{nullptr, nullptr, nullptr, nullptr};
+    size_t lane_sum_capacity = 0, pool_entry_capacity = 0, pending_capacity = 0;
     size_t staging_bytes = 0;
     unsigned long long* d_rays = nullptr;
 
@@ -82,7 +82,7 @@ uint32_t env_or(const char* name, long fallback, long lo, long hi) {
     return (uint32_t)(v < lo ? lo : v > hi ? hi : v);
 }
 uint32_t pool_threshold() { static const uint32_t v = env_or("RT_POOL_THRESHOLD", 32, 1, 63); return v; }
-uint32_t pool_max_samples() { static const uint32_t v = env_or("RT_POOL_MAX_SAMPLES", 8, 0, 1 << 20); return v; }
+uint32_t pool_max_samples() { static const uint32_t v = env_or("RT_POOL_MAX_SAMPLES", 12, 0, 1 << 20); return v; }
 
 struct Launch {
     rt::KernelParams kp;
@@ -275,6 +275,13 @@ rt_status ensure_workspace(rt_context* ctx, const Launch& L) {
         RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.lane_sums, streams * sizeof(float4)));
         ctx->lane_sum_capacity = streams;
     }
+    const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
+    if (pixel_count > ctx->pending_capacity) {
+        if (ctx->ws.pending) { RT_HIP_CHECK(ctx, hipFree(ctx->ws.pending)); ctx->ws.pending = nullptr; }
+        ctx->pending_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.pending, pixel_count));
+        ctx->pending_capacity = pixel_count;
+    }
     if (L.kp.pool_capacity > ctx->pool_entry_capacity) {
         if (ctx->ws.pool) { RT_HIP_CHECK(ctx, hipFree(ctx->ws.pool)); ctx->ws.pool = nullptr; }
         ctx->pool_entry_capacity = 0;
@@ -405,6 +412,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
     if (ctx->ws.lane_sums) (void)hipFree(ctx->ws.lane_sums);
     if (ctx->ws.pool) (void)hipFree(ctx->ws.pool);
+    if (ctx->ws.pending) (void)hipFree(ctx->ws.pending);
     if (ctx->ws.pool_count) (void)hipFree(ctx->ws.pool_count);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -552,7 +560,7 @@ rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint
         RT_HIP_CHECK(ctx, launch(ctx, L, 2, d_pixels, d_radiance, rays, ctx->ws, stream));
         const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
         hipLaunchKernelGGL(rt::pixel_combine_kernel, dim3((uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS)),
-                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ctx->ws.lane_sums, d_pixels, d_radiance);
+                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ctx->ws.lane_sums, ctx->ws.pending, d_pixels, d_radiance);
         RT_HIP_CHECK(ctx, hipGetLastError());
     }
     if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));

@@ -46,7 +46,8 @@ struct KernelParams {
 
 // Device workspace of the tail compaction: per-stream sums, the pool of unfinished streams and its fill count.
 struct Workspace {
-    float4* lane_sums;        // [pixel * lanes_per_pixel + batch]: finished sum of that stream (xyz)
+    float4* lane_sums;        // [pixel * lanes_per_pixel + batch]: finished sum of that stream (xyz), pending pixels only
+    uint8_t* pending;         // [pixel]: 1 if the pixel has to be assembled from lane_sums
     uint4* pool;              // POOL_VEC4 x uint4 per deposited stream
     uint32_t* pool_count;     // streams deposited by STAGE 1
 };
@@ -523,7 +524,7 @@ constexpr int BLOCK_THREADS = 256;   // resolve_kernel
 // samples left to start: finished lanes store their stream's sum in `lane_sums`, unfinished ones deposit
 // their complete state (stream, sample count, partial sum, pending ray) in the pool.  STAGE 2 runs
 // persistent waves whose lanes take deposited streams from the pool, one after another, and run them to
-// the end with the same loop.  pixel_combine_kernel then adds the lanes_per_pixel sums of every pixel in
+// the end with the same loop.  pixel_combine_kernel then adds the lanes_per_pixel sums of every pixel with a deposited stream in
 // the order of the STAGE 0 tree and writes the pixel.  A stream is computed by the same operations in the
 // same order wherever it runs, so the results are those of STAGE 0 bit for bit.
 template <int IMODE, int RMODE, bool MIXED, int STAGE>
@@ -739,6 +740,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
 
     // ---- epilogue ------------------------------------------------------------------
     ray_count += pixel_rays;
+    bool pixel_pending = false;           // STAGE 1: some stream of the lane's pixel was handed over
     if (RMODE == RT_RNG_PIXEL && STAGE != 0) {
         // Finished streams leave their sum, unfinished ones (STAGE 1 only) their state.
         const unsigned long long unfinished = __ballot(in_path);
@@ -758,11 +760,18 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 e[3] = make_uint4(__float_as_uint(next_dir.z), __float_as_uint(attenuation.x), __float_as_uint(attenuation.y), __float_as_uint(attenuation.z));
                 e[4] = make_uint4(__float_as_uint(result.x), __float_as_uint(result.y), __float_as_uint(result.z), 0u);
             }
-        } else if (STAGE == 1 && pixel_valid) {
-            ws.lane_sums[sid] = make_float4(pixel_sum.x, pixel_sum.y, pixel_sum.z, 0.0f);
+        }
+        if (STAGE == 1) {
+            // A pixel whose lanes_per_pixel streams all ended in this wave is finished here, like in STAGE 0;
+            // the others wait for pixel_combine_kernel, which reads the per-stream sums.
+            const uint32_t lane = threadIdx.x & 63u, width_mask = p.lanes_per_pixel - 1u;
+            const unsigned long long group = (p.lanes_per_pixel == 64u ? ~0ull : ((1ull << p.lanes_per_pixel) - 1ull)) << (lane & ~width_mask);
+            pixel_pending = (unfinished & group) != 0ull;
+            if (pixel_pending && !in_path && pixel_valid) ws.lane_sums[sid] = make_float4(pixel_sum.x, pixel_sum.y, pixel_sum.z, 0.0f);
+            if (pixel_valid && (lane & width_mask) == 0u) ws.pending[(size_t)ly * p.width + x] = pixel_pending ? 1 : 0;
         }
     }
-    if (RMODE == RT_RNG_PIXEL && STAGE == 0) {
+    if (RMODE == RT_RNG_PIXEL && STAGE != 2) {
         // Pairwise tree over the lanes_per_pixel partial sums of each pixel.
         for (uint32_t stride = 1; stride < p.lanes_per_pixel; stride <<= 1) {
             float sx = __shfl_down(pixel_sum.x, stride);
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             float sz = __shfl_down(pixel_sum.z, stride);
             if (((threadIdx.x % p.lanes_per_pixel) & (2 * stride - 1)) == 0) pixel_sum = pixel_sum + mk(sx, sy, sz);
         }
-        if (pixel_valid && (threadIdx.x % p.lanes_per_pixel) == 0)
+        if (pixel_valid && !pixel_pending && (threadIdx.x % p.lanes_per_pixel) == 0)
             emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
     }
     // Ray counter: one 64-bit atomic per wave (main.cpp:397).
@@ -785,7 +794,7 @@ __global__ void clear_counter_kernel(unsigned long long* counter, uint32_t* pool
     if (pool_count) *pool_count = 0u;
 }
 
-// Last step of the compacted render: the pixel is the pairwise tree over its lanes_per_pixel stream sums,
+// Last step of the compacted render, for the pixels STAGE 1 left pending: the pixel is the pairwise tree over its lanes_per_pixel stream sums,
 // in the order of the in-wave tree of STAGE 0 (halves added left + right), then color / sampleSize and pack.
 __device__ inline V3 tree_sum(const float4* sums, uint32_t n) {   // n: power of two <= 64
     V3 partial[7];   // partial[l]: sum of a completed left block of 2^l streams waiting for its right neighbour
@@ -799,9 +808,10 @@ __device__ inline V3 tree_sum(const float4* sums, uint32_t n) {   // n: power of
     return v;
 }
 __global__ __launch_bounds__(BLOCK_THREADS) void pixel_combine_kernel(KernelParams p, const float4* __restrict__ lane_sums,
+                                                                      const uint8_t* __restrict__ pending,
                                                                       uint32_t* __restrict__ pixels, float* __restrict__ radiance) {
     const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-    if (i >= (size_t)p.local_rows * p.width) return;
+    if (i >= (size_t)p.local_rows * p.width || !pending[i]) return;
     emit_pixel(p, tree_sum(lane_sums + i * p.lanes_per_pixel, p.lanes_per_pixel), i, pixels, radiance);
 }
 

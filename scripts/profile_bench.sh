@@ -20,7 +20,7 @@ import time, numpy as np
 from raytracer_amd import binding as B
 from raytracer_amd.host_scene import build_scene
 ctx = B.Context(0); ctx.upload_world(build_scene("cornell"))
-p = B.default_params(1920, 1080, 256, lanes_per_pixel=2)
+p = B.default_params(1920, 1080, 256, lanes_per_pixel=4, flags=B.FLAG_COMPACT_TAILS)
 ctx.render(p, want_radiance=False)
 ts = []
 for _ in range(5):

@@ -20,16 +20,17 @@ lines += ["## rocprofv3 --kernel-trace --stats", "", "| kernel | calls | total n
 kernel_ns = None
 for r in stats:
     lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
-    if "render_kernel" in r["Name"]:
-        kernel_ns = float(r["AverageNs"])
+    if "rt::render_kernel" in r["Name"] or "rt::pixel_combine_kernel" in r["Name"]:
+        # one render = one launch of each of these kernels (a single one without tail compaction)
+        kernel_ns = (kernel_ns or 0.0) + float(r["AverageNs"])
 counters = collections.OrderedDict()
 meta = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        if "rt::render_kernel" in r["Kernel_Name"] or "rt::pixel_combine_kernel" in r["Kernel_Name"]:
             counters[r["Counter_Name"]] = counters.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
-lines += ["", "## render kernel: dispatch", "", "```", json.dumps(meta), "```", "", "## render kernel: counters (one --pmc pass per group, summed over the chip)", "",
+lines += ["", "## render kernels (counters summed over the kernels of one render): dispatch of the last one", "", "```", json.dumps(meta), "```", "", "## render kernel: counters (one --pmc pass per group, summed over the chip)", "",
           "| counter | value |", "|---|---|"]
 for k, v in counters.items():
     lines.append(f"| {k} | {v:.6g} |")
