@@ -488,3 +488,7 @@ def test_random_scenes_bit_exact(ctx, seed):
                                                           lanes_per_pixel=int(rng.choice([1, 2, 4]))))
         check_against_oracle(ctx, scene, B.default_params(w, h, spp, intersect_mode=imode, max_bounces=bounces,
                                                           rng_mode=B.RNG_ROW_SERIAL, rows_per_order=int(rng.choice([1, 3]))))
+    # the compacted launch sequence, at a sample count that makes waves hand streams over
+    lanes = int(rng.choice([1, 2, 4]))
+    check_against_oracle(ctx, scene, B.default_params(w, h, 64 * lanes, max_bounces=bounces, lanes_per_pixel=lanes,
+                                                      flags=B.FLAG_COMPACT_TAILS))
