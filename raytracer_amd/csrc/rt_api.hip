@@ -180,7 +180,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         if (capacity > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "image too large for RT_FLAG_COMPACT_TAILS");
         k.pool_capacity = (uint32_t)capacity;
         // Stage 2 runs persistent waves that fetch streams until the pool is empty: four waves per SIMD.
-        const uint64_t stage2_waves = (uint64_t)ctx->props.multiProcessorCount * 16u;
+        const uint64_t stage2_waves = (uint64_t)ctx->props.multiProcessorCount * env_or("RT_STAGE2_WAVES_PER_CU", 16, 1, 64);
         const uint64_t stage2_blocks = (stage2_waves * 64u + out->block_threads - 1) / out->block_threads;
         out->stage2_blocks = (uint32_t)(stage2_blocks < blocks ? stage2_blocks : blocks);
     }
