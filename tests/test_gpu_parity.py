@@ -278,6 +278,12 @@ def test_errors(ctx, cornell):
     with pytest.raises(B.RtError) as e:
         fresh.render(B.default_params(8, 8, 1))
     assert e.value.status == 4                                  # RT_ERR_NO_WORLD
+    with pytest.raises(B.RtError) as e:
+        fresh.reserve(B.default_params(8, 8, 256, flags=B.FLAG_COMPACT_TAILS))
+    assert e.value.status == 4
+    with pytest.raises(B.RtError) as e:
+        fresh.resolve(np.zeros((4, 4, 3), dtype=np.float32), 0)
+    assert e.value.status == 1 and "sample count" in str(e.value)
     fresh.close()
     ctx.upload_world(cornell)
     bad = [dict(samples_per_pixel=0), dict(width=0), dict(row_begin=5, row_end=5), dict(row_end=99),
