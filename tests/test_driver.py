@@ -54,3 +54,16 @@ def test_driver_row_serial_mode_matches_the_reference_fixture(tmp_path, golden_d
     diff = np.abs(((pixels[..., None] >> np.array([16, 8, 0], dtype=np.uint32)) & 255).astype(int) -
                   ((g["pixels"][..., None] >> np.array([16, 8, 0], dtype=np.uint32)) & 255).astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_driver_compact_option_writes_the_same_file(tmp_path):
+    """--compact (RT_FLAG_COMPACT_TAILS) changes the launch schedule, not the image or the ray count."""
+    common = [str(DRIVER), "--scene", "glass_spheres", "--width", "160", "--height", "90", "--spp", "256", "--bounces", "32",
+              "--lanes-per-pixel", "4"]
+    plain = subprocess.run(common + ["--out", str(tmp_path / "plain.bmp")], capture_output=True, text=True, timeout=120)
+    compact = subprocess.run(common + ["--compact", "--out", str(tmp_path / "compact.bmp")], capture_output=True, text=True, timeout=120)
+    assert plain.returncode == 0 and compact.returncode == 0, plain.stderr + compact.stderr
+    rays = lambda out: re.search(r"Total computed rays: (\d+)", out).group(1)
+    assert rays(plain.stdout) == rays(compact.stdout)
+    assert (tmp_path / "plain.bmp").read_bytes() == (tmp_path / "compact.bmp").read_bytes()
