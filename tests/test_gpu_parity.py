@@ -353,6 +353,32 @@ def test_tail_compaction_changes_nothing_but_the_schedule(ctx, cornell, spheres,
     assert np.array_equal(ctx.render(p)[0], plain[0])
 
 
+def test_tail_compaction_over_random_parameters(ctx, cornell, spheres):
+    """120 random combinations of scene, image size (from 1x1), lanes per pixel (1..64), bounce cap, intersect
+    routine, batch offset, row bands and sum output: compacted and single-launch renders are identical."""
+    rng = np.random.default_rng(7)
+    scenes = [cornell, spheres, build_scene("glass_spheres", 3), build_scene("random_spheres", 37, 2)]
+    for it in range(120):
+        ctx.upload_world(scenes[it % 4])
+        lanes = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        kw = dict(lanes_per_pixel=lanes, max_bounces=int(rng.choice([1, 4, 8, 32])), intersect_mode=int(rng.integers(0, 2)),
+                  batch_offset=int(rng.integers(0, 1000)))
+        if rng.random() < 0.3 and h > 8:
+            kw.update(band_rows=int(rng.choice([1, 4, 8])), band_count=int(rng.integers(2, 5)))
+            kw["band_index"] = int(rng.integers(0, kw["band_count"]))
+        if rng.random() < 0.3:
+            kw["flags"] = B.FLAG_OUTPUT_SUM
+        p = B.default_params(w, h, lanes * int(rng.integers(52, 90)), **kw)
+        if B.local_row_count(p) == 0:
+            continue
+        plain = ctx.render(p)
+        p.flags |= B.FLAG_COMPACT_TAILS
+        compact = ctx.render(p)
+        assert compact[2] == plain[2] and np.array_equal(compact[0], plain[0]) and \
+            np.array_equal(bits(compact[1]), bits(plain[1])), (it, w, h, kw)
+
+
 def test_compacted_bench_workload_bit_exact(ctx, cornell):
     """The benchmarked launch sequence (Cornell 1920x1080 at 256 spp, 4 lanes per pixel, compacted tails)
     against the CPU oracle."""
