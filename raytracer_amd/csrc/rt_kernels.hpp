@@ -485,7 +485,7 @@ __device__ __forceinline__ bool refract(V3 incident, V3 normal, float ri, float 
     }
     float discriminant = 1 - ratio * ratio * (1 - cos_i * cos_i);
     if (discriminant < 0) return false;
-    out = incident * ratio + hit_normal * (ratio * cos_i - __builtin_sqrtf(discriminant));
+    out = incident * ratio + hit_normal * (ratio * cos_i - sqrt_exact(discriminant));
     return true;
 }
 
