@@ -113,7 +113,14 @@ enum {  /* rt_render_params.flags */
      * small kernel adds the per-stream sums of each pixel.  Same results bit for bit, fewer idle lanes.  Uses
      * a workspace owned by the context (16 B per stream + 40 B per lane), allocated by the first render that
      * needs it or by rt_reserve: that call allocates, later ones do not. */
-    RT_FLAG_COMPACT_TAILS = 4u
+    RT_FLAG_COMPACT_TAILS = 4u,
+    /* Progressive rendering: radiance (which must be given; pixels must be NULL) is not overwritten but added
+     * to: radiance[i] = radiance[i] + this render's sample sum, as a host loop `sum += pass` would do.  With
+     * the device entry point the buffer is the caller's.  With rt_render / rt_render_multi the running sum
+     * lives in the context: it is started by a render of the same rows with RT_FLAG_OUTPUT_SUM (or set with
+     * rt_load_accumulator), every RT_FLAG_ACCUMULATE render adds to it, and `radiance` (may be NULL) receives
+     * a copy.  Resolve the image at the end with rt_resolve / rt_resolve_device. */
+    RT_FLAG_ACCUMULATE = 8u
 };
 
 typedef struct rt_render_params {
@@ -190,6 +197,10 @@ rt_status rt_render_device(rt_context* context, const rt_render_params* params,
 /* Allocates now whatever device workspace rt_render_device would allocate on its first call with these
  * parameters (RT_FLAG_COMPACT_TAILS), so that the render calls themselves allocate nothing. */
 rt_status rt_reserve(rt_context* context, const rt_render_params* params);
+
+/* Sets the running sum that RT_FLAG_ACCUMULATE renders through rt_render add to (a sum loaded back from a
+ * checkpoint): local_rows*width*3 floats, the rows of `params` in the compact order rt_render returns. */
+rt_status rt_load_accumulator(rt_context* context, const rt_render_params* params, const float* radiance_sum);
 
 /* Multi-GPU render into HOST memory: the rows [row_begin,row_end) of `params` are cut into bands of
  * 8 rows, context i renders bands i, i + n, ... concurrently (one host thread per context, the

@@ -21,13 +21,13 @@ LIB_PATH = pathlib.Path(os.environ.get("RT_HIP_LIBRARY", _PKG / "librt_hip.so"))
 RT_OK = 0
 RNG_ROW_SERIAL, RNG_PIXEL = 0, 1
 INTERSECT_WIDE8, INTERSECT_SCALAR = 0, 1
-FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL, FLAG_COMPACT_TAILS = 1, 2, 4
+FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL, FLAG_COMPACT_TAILS, FLAG_ACCUMULATE = 1, 2, 4, 8
 
 # Every symbol include/rt_hip.h declares.
 EXPORTS = (
     "rt_abi_version", "rt_status_string", "rt_create", "rt_destroy", "rt_error_string",
     "rt_get_device_info", "rt_default_params", "rt_local_row_count", "rt_global_row",
-    "rt_upload_world", "rt_reserve", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_resolve",
+    "rt_upload_world", "rt_reserve", "rt_load_accumulator", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_resolve",
     "rt_last_kernel_ms",
 )
 
@@ -112,6 +112,8 @@ def load_library() -> C.CDLL:
     L.rt_upload_world.argtypes = [C.c_void_p, C.POINTER(World)]
     L.rt_reserve.restype = C.c_int
     L.rt_reserve.argtypes = [C.c_void_p, C.POINTER(RenderParams)]
+    L.rt_load_accumulator.restype = C.c_int
+    L.rt_load_accumulator.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.rt_render.restype = C.c_int
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.rt_render_device.restype = C.c_int
@@ -213,6 +215,13 @@ class Context:
     def reserve(self, params: RenderParams):
         """Allocates the device workspace a render with these parameters needs (FLAG_COMPACT_TAILS)."""
         self._check(self._lib.rt_reserve(self._h, C.byref(params)))
+
+    def load_accumulator(self, params: RenderParams, radiance_sum: np.ndarray):
+        """Sets the running sum that FLAG_ACCUMULATE renders add to: [local rows, W, 3] float32."""
+        radiance_sum = np.ascontiguousarray(radiance_sum, dtype=np.float32)
+        if radiance_sum.shape != (local_row_count(params), params.width, 3):
+            raise ValueError("radiance_sum must be [local rows, width, 3]")
+        self._check(self._lib.rt_load_accumulator(self._h, C.byref(params), _ptr(radiance_sum)))
 
     def render(self, params: RenderParams, want_pixels=True, want_radiance=True):
         """Synchronous render to host memory: (pixels [rows,W] uint32, radiance [rows,W,3] f32, rays)."""

@@ -38,6 +38,9 @@ struct rt_context {
     uint32_t* d_pixels = nullptr;
     float* d_radiance = nullptr;
     size_t pixel_capacity = 0, radiance_capacity = 0;
+    // running sum of RT_FLAG_ACCUMULATE renders through rt_render: d_radiance, valid for the rows of this key
+    bool accumulator_valid = false;
+    uint32_t accumulator_key[6] = {0, 0, 0, 0, 0, 0};
     void* h_staging = nullptr;       // pinned host buffer the results are copied through
     // workspace of RT_FLAG_COMPACT_TAILS renders; grow-only
     rt::Workspace ws{nullptr, nullptr, nullptr, nullptr};
@@ -127,7 +130,8 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     k.max_bounces = p->max_bounces;
     k.min_hit = p->min_hit_distance; k.plane_tol = p->plane_tolerance;
     k.seed_constant = p->seed_constant;
-    k.output_sum = (p->flags & RT_FLAG_OUTPUT_SUM) ? 1u : 0u;
+    k.accumulate = (p->flags & RT_FLAG_ACCUMULATE) ? 1u : 0u;
+    k.output_sum = (p->flags & (RT_FLAG_OUTPUT_SUM | RT_FLAG_ACCUMULATE)) ? 1u : 0u;
     out->imode = (int)p->intersect_mode;
     out->rmode = (int)p->rng_mode;
     k.lds_words = ctx->lds_words;
@@ -260,6 +264,7 @@ rt_status ensure_output_capacity(rt_context* ctx, size_t count, bool want_pixels
     if (want_radiance && count > ctx->radiance_capacity) {
         if (ctx->d_radiance) { RT_HIP_CHECK(ctx, hipFree(ctx->d_radiance)); ctx->d_radiance = nullptr; }
         ctx->radiance_capacity = 0;
+        ctx->accumulator_valid = false;
         RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_radiance, count * 3 * sizeof(float)));
         ctx->radiance_capacity = count;
     }
@@ -314,13 +319,23 @@ rt_status render_to_host(rt_context* ctx, const rt_render_params* params, uint32
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t width = L.kp.width, rows = L.kp.local_rows, count = rows * width;
     const size_t pixel_bytes = pixels ? count * sizeof(uint32_t) : 0, radiance_bytes = radiance ? count * 3 * sizeof(float) : 0;
-    st = ensure_output_capacity(ctx, count, pixels != nullptr, radiance != nullptr);
+    // The context's radiance buffer doubles as the running sum of progressive renders: a sum render starts
+    // it, accumulating renders of the same rows add to it, anything else that writes the buffer ends it.
+    const bool accumulate = params->flags & RT_FLAG_ACCUMULATE, starts_sum = !accumulate && (params->flags & RT_FLAG_OUTPUT_SUM);
+    const uint32_t key[6] = {params->width, params->row_begin, params->row_end, params->band_rows, params->band_index, params->band_count};
+    if (accumulate && (!ctx->accumulator_valid || std::memcmp(key, ctx->accumulator_key, sizeof key) != 0))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                    "RT_FLAG_ACCUMULATE: no running sum for these rows (render them with RT_FLAG_OUTPUT_SUM or call rt_load_accumulator first)");
+    const bool device_radiance = radiance || accumulate || starts_sum;
+    st = ensure_output_capacity(ctx, count, pixels != nullptr, device_radiance);
     if (st != RT_OK) return st;
     st = ensure_staging(ctx, pixel_bytes + radiance_bytes + 16);
     if (st != RT_OK) return st;
-    st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, radiance ? ctx->d_radiance : nullptr,
+    if (device_radiance && !accumulate) ctx->accumulator_valid = false;
+    st = rt_render_device(ctx, params, pixels ? ctx->d_pixels : nullptr, device_radiance ? ctx->d_radiance : nullptr,
                           reinterpret_cast<uint64_t*>(ctx->d_rays), nullptr);
     if (st != RT_OK) return st;
+    if (starts_sum) { ctx->accumulator_valid = true; std::memcpy(ctx->accumulator_key, key, sizeof key); }
     char* stage = static_cast<char*>(ctx->h_staging);
     if (pixels) RT_HIP_CHECK(ctx, hipMemcpyAsync(stage, ctx->d_pixels, pixel_bytes, hipMemcpyDeviceToHost, nullptr));
     if (radiance) RT_HIP_CHECK(ctx, hipMemcpyAsync(stage + pixel_bytes, ctx->d_radiance, radiance_bytes, hipMemcpyDeviceToHost, nullptr));
@@ -530,6 +545,7 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
     ctx->sphere_tag_offset = images[0][rt::H_OFF_SPHERE_TAGS];
     ctx->mixed = w->sphere_count && w->rectangle_count;
     ctx->has_world = true;
+    ctx->accumulator_valid = false;
     return RT_OK;
 }
 
@@ -540,6 +556,8 @@ rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint
     Launch L;
     rt_status st = validate_and_plan(ctx, params, &L);
     if (st != RT_OK) return st;
+    if ((params->flags & RT_FLAG_ACCUMULATE) && (!d_radiance || d_pixels))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_ACCUMULATE needs a radiance buffer and no pixel buffer");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
@@ -576,6 +594,24 @@ rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
     if (st != RT_OK) return st;
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     return L.compact ? ensure_workspace(ctx, L) : RT_OK;
+}
+
+rt_status rt_load_accumulator(rt_context* ctx, const rt_render_params* params, const float* radiance_sum) {
+    if (!ctx || !radiance_sum) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L);
+    if (st != RT_OK) return st;
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t count = (size_t)L.kp.local_rows * L.kp.width;
+    st = ensure_output_capacity(ctx, count, false, true);
+    if (st != RT_OK) return st;
+    ctx->accumulator_valid = false;
+    RT_HIP_CHECK(ctx, hipMemcpy(ctx->d_radiance, radiance_sum, count * 3 * sizeof(float), hipMemcpyHostToDevice));
+    const uint32_t key[6] = {params->width, params->row_begin, params->row_end, params->band_rows, params->band_index, params->band_count};
+    std::memcpy(ctx->accumulator_key, key, sizeof key);
+    ctx->accumulator_valid = true;
+    return RT_OK;
 }
 
 rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays) {
@@ -651,6 +687,7 @@ rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve: bad sum pointer, pixel count or sample count");
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     rt_status st = ensure_output_capacity(ctx, (size_t)pixel_count, pixels != nullptr, radiance_mean != nullptr);
+    if (radiance_mean) ctx->accumulator_valid = false;   // the mean is staged in the radiance buffer
     if (st != RT_OK) return st;
     float* d_sum = nullptr;
     const size_t sum_bytes = (size_t)pixel_count * 3 * sizeof(float);

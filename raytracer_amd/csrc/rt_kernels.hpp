@@ -36,7 +36,7 @@ struct KernelParams {
     uint32_t rows_per_order, order_count;               // ROW_SERIAL
     uint32_t lanes_per_pixel, samples_per_lane, batch_offset;  // PIXEL
     uint32_t tile_w, tile_h, tiles_x, tiles_y;          // PIXEL: pixels of one wave
-    uint32_t output_sum;
+    uint32_t output_sum, accumulate;                    // radiance receives the sample sum / is added to
     uint32_t pool_threshold, pool_max_samples, pool_capacity;             // tail compaction (STAGE 1 and 2), see render_kernel
     uint32_t lds_words;                                 // leading part of the scene image staged in LDS
     uint32_t sphere_count, sphere_offset, sphere_tag_offset;   // sphere sections of the global image (words)
@@ -506,6 +506,8 @@ __device__ __forceinline__ void emit_pixel(const KernelParams& p, V3 sum, size_t
     if (pixels) pixels[index] = pack_srgb(mean);
     if (radiance) {
         V3 out = p.output_sum ? sum : mean;
+        if (p.accumulate)   // progressive rendering: running sum + this pass, the order in which a host would add them
+            out = mk(radiance[3 * index + 0], radiance[3 * index + 1], radiance[3 * index + 2]) + sum;
         radiance[3 * index + 0] = out.x;
         radiance[3 * index + 1] = out.y;
         radiance[3 * index + 2] = out.z;

@@ -111,13 +111,24 @@ def render_progressive(ctx, params, passes: int, accumulator: Accumulator | None
                                      settings_hash=settings_hash(params))
     if (acc.width, acc.height, acc.lanes_per_pixel) != (params.width, params.height, params.lanes_per_pixel):
         raise ValueError("accumulator belongs to another image size or lanes_per_pixel")
+    # The running sum stays in the context (FLAG_ACCUMULATE adds each pass to it on the GPU, in the order a host
+    # loop `sum += pass` would); it is copied back for a checkpoint and after the last pass.
     flags, offset = params.flags, params.batch_offset
+    started = acc.samples > 0
     try:
-        params.flags = flags | B.FLAG_OUTPUT_SUM
-        for _ in range(passes):
+        if started:
+            ctx.load_accumulator(params, acc.sum)
+        for i in range(passes):
             params.batch_offset = acc.next_batch
-            _, pass_sum, rays = ctx.render(params, want_pixels=False)
-            acc.add_pass(pass_sum, params.samples_per_pixel, rays)
+            params.flags = (flags & ~(B.FLAG_OUTPUT_SUM | B.FLAG_ACCUMULATE)) | (B.FLAG_ACCUMULATE if started else B.FLAG_OUTPUT_SUM)
+            need_sum = checkpoint is not None or i + 1 == passes
+            _, total, rays = ctx.render(params, want_pixels=False, want_radiance=need_sum)
+            started = True
+            if need_sum:
+                acc.sum = total
+            acc.samples += params.samples_per_pixel
+            acc.next_batch += acc.lanes_per_pixel
+            acc.rays += rays
             if checkpoint is not None:
                 acc.write(checkpoint)
     finally:

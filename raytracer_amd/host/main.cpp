@@ -159,14 +159,37 @@ int main(int argc, char** argv) {
             acc = std::move(loaded);
             std::printf("Resumed at %u samples per pixel\n", acc.samples);
         }
-        std::vector<float> pass_sum(acc.sum.size());
-        params.flags |= RT_FLAG_OUTPUT_SUM;
+        // The running sum stays on the GPUs (RT_FLAG_ACCUMULATE); it comes back to the host only where it is
+        // needed: for a checkpoint and for the final resolve.
+        const uint32_t width = (uint32_t)opt.width;
+        if (!opt.resume.empty()) {
+            // hand every GPU the rows it renders (interleaved 8-row bands, as rt_render_multi deals them)
+            for (size_t g = 0; g < contexts.size() && st == RT_OK; ++g) {
+                rt_render_params share = params;
+                share.band_rows = contexts.size() > 1 ? 8u : 0u;
+                share.band_index = (uint32_t)g;
+                share.band_count = (uint32_t)contexts.size();
+                const uint32_t rows = rt_local_row_count(&share);
+                if (rows == 0) continue;
+                std::vector<float> compact((size_t)rows * width * 3);
+                for (uint32_t local = 0; local < rows; ++local)
+                    std::memcpy(&compact[(size_t)local * width * 3], &acc.sum[(size_t)rt_global_row(&share, local) * width * 3],
+                                (size_t)width * 3 * sizeof(float));
+                st = rt_load_accumulator(contexts[g], &share, compact.data());
+            }
+        }
+        bool started = !opt.resume.empty();
         for (unsigned pass = 0; pass < opt.passes && st == RT_OK; ++pass) {
             params.batch_offset = acc.next_batch;
+            params.flags = (params.flags & ~(uint32_t)(RT_FLAG_OUTPUT_SUM | RT_FLAG_ACCUMULATE)) |
+                           (started ? RT_FLAG_ACCUMULATE : RT_FLAG_OUTPUT_SUM);
+            const bool need_sum = !opt.checkpoint.empty() || pass + 1 == opt.passes;
             uint64_t pass_rays = 0;
-            st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, nullptr, pass_sum.data(), &pass_rays);
+            st = rt_render_multi(contexts.data(), (uint32_t)contexts.size(), &params, nullptr, need_sum ? acc.sum.data() : nullptr,
+                                 &pass_rays);
             if (st != RT_OK) break;
-            acc.AddPass(pass_sum.data(), opt.spp, pass_rays);
+            started = true;
+            acc.Advance(opt.spp, pass_rays);
             rays += pass_rays;
             if (!opt.checkpoint.empty() && !WriteAccumulatorFile(acc, opt.checkpoint.c_str())) {
                 std::fprintf(stderr, "cannot write %s\n", opt.checkpoint.c_str());

@@ -35,6 +35,10 @@ void Accumulator::Reset(uint32_t w, uint32_t h) {
 
 void Accumulator::AddPass(const float* pass_sum, uint32_t pass_samples, uint64_t pass_rays) {
     for (size_t i = 0; i < sum.size(); ++i) sum[i] += pass_sum[i];
+    Advance(pass_samples, pass_rays);
+}
+
+void Accumulator::Advance(uint32_t pass_samples, uint64_t pass_rays) {
     samples += pass_samples;
     next_batch += lanes_per_pixel;
     rays += pass_rays;

@@ -33,6 +33,8 @@ struct Accumulator {
     // sum += pass (element by element, in pass order: the result does not depend on where a
     // checkpoint was taken); advances samples, next_batch and rays.
     void AddPass(const float* pass_sum, uint32_t pass_samples, uint64_t pass_rays);
+    // The counters' part of AddPass, for a sum that was accumulated elsewhere (on the GPU) and copied into `sum`.
+    void Advance(uint32_t pass_samples, uint64_t pass_rays);
 };
 
 // FNV-1a over the world's arrays and camera / over the parameters that define the estimator

@@ -146,6 +146,57 @@ def test_progressive_passes_resume_bit_exactly(tmp_path, spheres):
 
 
 @pytest.mark.gpu
+def test_accumulate_flag_equals_host_addition(spheres):
+    """RT_FLAG_ACCUMULATE adds a pass to the running sum on the GPU exactly as `sum += pass` does on the host:
+    through rt_render (sum kept in the context), through rt_render_device (caller's buffer), with tail
+    compaction, and after rt_load_accumulator; misuse is refused."""
+    import torch
+    with B.Context(0) as ctx:
+        ctx.upload_world(spheres)
+        w, h, spp, lanes = 120, 67, 128, 2
+        passes = []
+        for i in range(3):
+            p = B.default_params(w, h, spp, lanes_per_pixel=lanes, batch_offset=i * lanes, flags=B.FLAG_OUTPUT_SUM)
+            passes.append(ctx.render(p, want_pixels=False)[1])
+        host = passes[0].copy()
+        host += passes[1]
+        host += passes[2]
+        # context-kept running sum
+        for i in range(3):
+            flags = (B.FLAG_ACCUMULATE if i else B.FLAG_OUTPUT_SUM) | (B.FLAG_COMPACT_TAILS if i == 2 else 0)
+            p = B.default_params(w, h, spp, lanes_per_pixel=lanes, batch_offset=i * lanes, flags=flags)
+            _, total, _ = ctx.render(p, want_pixels=False, want_radiance=(i == 2))
+        assert np.array_equal(_bits(total), _bits(host))
+        # caller's device buffer
+        dev = torch.device("cuda", 0)
+        acc = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        rays = torch.zeros(1, dtype=torch.int64, device=dev)
+        for i in range(3):
+            p = B.default_params(w, h, spp, lanes_per_pixel=lanes, batch_offset=i * lanes, flags=B.FLAG_ACCUMULATE)
+            ctx.render_device(p, None, acc.data_ptr(), rays.data_ptr(), None)
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(_bits(acc.cpu().numpy()), _bits(host))     # 0 + a + b + c = a + b + c in float for sums >= +0
+        # a sum loaded back, then one more pass
+        p = B.default_params(w, h, spp, lanes_per_pixel=lanes, batch_offset=2 * lanes, flags=B.FLAG_ACCUMULATE)
+        two = passes[0].copy(); two += passes[1]
+        ctx.load_accumulator(p, two)
+        assert np.array_equal(_bits(ctx.render(p, want_pixels=False)[1]), _bits(host))
+        # misuse
+        with pytest.raises(B.RtError) as e:
+            ctx.render(p)                                    # pixels requested
+        assert e.value.status == 1 and "RT_FLAG_ACCUMULATE" in str(e.value)
+        other = B.default_params(w, h - 8, spp, lanes_per_pixel=lanes, flags=B.FLAG_ACCUMULATE)
+        with pytest.raises(B.RtError) as e:
+            ctx.render(other, want_pixels=False)             # no running sum for these rows
+        assert e.value.status == 1 and "running sum" in str(e.value)
+        ctx.upload_world(spheres)                            # a new world ends the running sum
+        with pytest.raises(B.RtError):
+            ctx.render(p, want_pixels=False)
+        with pytest.raises(B.RtError):
+            ctx.render_device(p, None, None, rays.data_ptr(), None)
+
+
+@pytest.mark.gpu
 def test_driver_checkpoint_and_resume(tmp_path):
     """raytracer --passes / --checkpoint / --resume: an interrupted render continued from its file gives the
     same BMP as the uninterrupted one, and the same sums as the library; a file from another scene is refused."""
