@@ -188,8 +188,9 @@ rt_status rt_render(rt_context* context, const rt_render_params* params,
 
 /* Same, with caller-owned DEVICE buffers, asynchronous on `hip_stream`
  * (a hipStream_t; NULL = the default stream).  *d_rays is zeroed by the call and
- * then accumulated into.  Allocates nothing and changes no kernel attribute: the call only enqueues
- * kernels on the stream, so it may be recorded into a HIP graph (stream capture) and replayed. */
+ * then accumulated into.  Allocates nothing (but see RT_FLAG_COMPACT_TAILS / rt_reserve) and changes no
+ * kernel attribute: the call only enqueues kernels on the stream, so it may be recorded into a HIP graph
+ * (stream capture) and replayed. */
 rt_status rt_render_device(rt_context* context, const rt_render_params* params,
                            uint32_t* d_pixels, float* d_radiance, uint64_t* d_rays,
                            void* hip_stream);
