@@ -195,6 +195,22 @@ rt_status rt_render_device(rt_context* context, const rt_render_params* params,
                            uint32_t* d_pixels, float* d_radiance, uint64_t* d_rays,
                            void* hip_stream);
 
+/* rt_render_device for callers that cannot allocate device memory at all (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): same arguments, same kernels, same results bit
+ * for bit, but the workspace of an RT_FLAG_COMPACT_TAILS render is a fixed 32 MiB array that is part of
+ * the library's code object (one copy per GPU, held until the process ends) instead of memory the context
+ * allocates, so the call never allocates or frees anything and needs no rt_reserve.  It has no counterpart
+ * in the reference.  Limit: with RT_FLAG_COMPACT_TAILS at most 2^20 pixels and 2^20 streams
+ * (local rows x width x lanes_per_pixel) per call, e.g. 1024x1024 at one lane per pixel or 640x400 at four;
+ * larger renders return RT_ERR_TOO_LARGE (without the flag there is no workspace and no limit).  The pool
+ * of handed-over streams takes what is left of the array (196,000 entries); when a render has more waves
+ * than that allows at the usual hand-over threshold, the threshold is lowered, which changes the schedule
+ * only.  Every call on a GPU shares that GPU's array, whatever its context or stream: calls that overlap
+ * in time on one GPU race on it and give wrong pixels; run them one after another. */
+rt_status rt_render_device_noalloc(rt_context* context, const rt_render_params* params,
+                                   uint32_t* d_pixels, float* d_radiance, uint64_t* d_rays,
+                                   void* hip_stream);
+
 /* Allocates now whatever device workspace rt_render_device would allocate on its first call with these
  * parameters (RT_FLAG_COMPACT_TAILS), so that the render calls themselves allocate nothing. */
 rt_status rt_reserve(rt_context* context, const rt_render_params* params);

@@ -27,7 +27,8 @@ FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL, FLAG_COMPACT_TAILS, FLAG_ACCUMULATE = 1, 2, 4
 EXPORTS = (
     "rt_abi_version", "rt_status_string", "rt_create", "rt_destroy", "rt_error_string",
     "rt_get_device_info", "rt_default_params", "rt_local_row_count", "rt_global_row",
-    "rt_upload_world", "rt_reserve", "rt_load_accumulator", "rt_render", "rt_render_device", "rt_render_multi", "rt_resolve_device", "rt_resolve",
+    "rt_upload_world", "rt_reserve", "rt_load_accumulator", "rt_render", "rt_render_device", "rt_render_device_noalloc",
+    "rt_render_multi", "rt_resolve_device", "rt_resolve",
     "rt_last_kernel_ms",
 )
 
@@ -118,6 +119,8 @@ def load_library() -> C.CDLL:
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.rt_render_device.restype = C.c_int
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_render_device_noalloc.restype = C.c_int
+    L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
     L.rt_render_multi.restype = C.c_int
     L.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_uint64)]
@@ -236,6 +239,11 @@ class Context:
                       d_rays: int | None, stream: int | None = None):
         """Asynchronous render into caller-owned device buffers (raw device addresses)."""
         self._check(self._lib.rt_render_device(self._h, C.byref(params), d_pixels, d_radiance, d_rays, stream))
+
+    def render_device_noalloc(self, params: RenderParams, d_pixels: int | None, d_radiance: int | None,
+                              d_rays: int | None, stream: int | None = None):
+        """render_device with the fixed per-GPU workspace: allocates nothing; refuses sizes the workspace cannot hold."""
+        self._check(self._lib.rt_render_device_noalloc(self._h, C.byref(params), d_pixels, d_radiance, d_rays, stream))
 
     def resolve_device(self, d_sum: int, pixel_count: int, total_samples: int, d_pixels: int | None,
                        d_mean: int | None, stream: int | None = None):

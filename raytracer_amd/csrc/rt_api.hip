@@ -20,8 +20,16 @@
 #include "rt_kernels.hpp"
 #include "rt_layout.hpp"
 
+// Workspace of rt_render_device_noalloc: one fixed array per GPU, part of the code object (each GPU the
+// library is loaded on holds its own copy until the process ends).  Host code never uses the array's
+// name as an address: rt_create asks the runtime for this device's copy (hipGetSymbolAddress) and the
+// context keeps that pointer.
+constexpr size_t STATIC_SCRATCH_BYTES = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 struct rt_context {
     int device = -1;
+    unsigned char* static_scratch = nullptr;   // this device's copy of `scratch`
     hipDeviceProp_t props{};
     std::string error;
 
@@ -95,7 +103,9 @@ struct Launch {
     uint32_t stage2_blocks = 0;
 };
 
-rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out) {
+// `max_pool_entries` (0 = no limit) caps the pool of handed-over streams: the hand-over threshold is lowered
+// until waves * threshold entries fit, and with no room at all the render is planned as a single launch.
+rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out, uint64_t max_pool_entries = 0) {
     if (!p) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->struct_size != sizeof(rt_render_params))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_params.struct_size %u != %zu (ABI mismatch)", p->struct_size,
@@ -180,6 +190,11 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         // A stage-1 wave hands over at most pool_threshold streams, so waves * threshold entries always suffice.
         k.pool_threshold = pool_threshold();
         k.pool_max_samples = pool_max_samples();
+        const uint64_t waves = blocks * (out->block_threads / 64u);
+        if (max_pool_entries && waves * k.pool_threshold > max_pool_entries) k.pool_threshold = (uint32_t)(max_pool_entries / waves);
+        if (k.pool_threshold == 0) out->compact = false;
+    }
+    if (out->compact) {
         const uint64_t capacity = blocks * (out->block_threads / 64u) * k.pool_threshold;
         if (capacity > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "image too large for RT_FLAG_COMPACT_TAILS");
         k.pool_capacity = (uint32_t)capacity;
@@ -361,6 +376,74 @@ rt_status render_to_host(rt_context* ctx, const rt_render_params* params, uint32
     return RT_OK;
 }
 
+// Layout of the fixed per-GPU workspace behind rt_render_device_noalloc (STATIC_SCRATCH_BYTES in all):
+//   [0, 256)                     fill count of the pool
+//   [256, 256 + 1 MiB)           one pending flag per pixel          -> at most 2^20 pixels
+//   [.., + 16 MiB)               one float4 sum per stream            -> at most 2^20 streams (pixels x lanes_per_pixel)
+//   rest (about 15 MiB)          pool of handed-over streams, 80 bytes each
+constexpr uint64_t STATIC_MAX_PIXELS = 1u << 20, STATIC_MAX_STREAMS = 1u << 20;
+constexpr size_t STATIC_PENDING_OFFSET = 256;
+constexpr size_t STATIC_LANE_SUMS_OFFSET = STATIC_PENDING_OFFSET + STATIC_MAX_PIXELS;
+constexpr size_t STATIC_POOL_OFFSET = STATIC_LANE_SUMS_OFFSET + STATIC_MAX_STREAMS * sizeof(float4);
+constexpr uint64_t STATIC_POOL_ENTRIES = (STATIC_SCRATCH_BYTES - STATIC_POOL_OFFSET) / (rt::POOL_VEC4 * sizeof(uint4));
+static_assert(STATIC_POOL_OFFSET % 256 == 0 && STATIC_POOL_OFFSET < STATIC_SCRATCH_BYTES, "static workspace layout");
+
+// Enqueues the kernels of one render on `hip_stream`.  static_workspace = false: the compacted render's
+// workspace is the context's (allocated by the first render that needs it, or by rt_reserve).
+// static_workspace = true: it is this GPU's fixed array and the call allocates nothing; sizes the array
+// cannot hold are refused.
+rt_status render_device(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
+                        uint64_t* d_rays, void* hip_stream, bool static_workspace) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
+    Launch L;
+    rt_status st = validate_and_plan(ctx, params, &L, static_workspace ? STATIC_POOL_ENTRIES : 0);
+    if (st != RT_OK) return st;
+    if ((params->flags & RT_FLAG_ACCUMULATE) && (!d_radiance || d_pixels))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_ACCUMULATE needs a radiance buffer and no pixel buffer");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
+    rt::Workspace ws = ctx->ws;
+    if (L.compact && static_workspace) {
+        const uint64_t pixel_count = (uint64_t)L.kp.local_rows * L.kp.width, streams = pixel_count * L.kp.lanes_per_pixel;
+        if (pixel_count > STATIC_MAX_PIXELS || streams > STATIC_MAX_STREAMS)
+            return fail(ctx, RT_ERR_TOO_LARGE,
+                        "rt_render_device_noalloc: %llu pixels x %u lanes per pixel exceed the fixed workspace (at most %llu pixels and %llu streams with RT_FLAG_COMPACT_TAILS)",
+                        (unsigned long long)pixel_count, L.kp.lanes_per_pixel, (unsigned long long)STATIC_MAX_PIXELS,
+                        (unsigned long long)STATIC_MAX_STREAMS);
+        unsigned char* base = ctx->static_scratch;   // this device's copy of the array, from hipGetSymbolAddress
+        ws.pool_count = reinterpret_cast<uint32_t*>(base);
+        ws.pending = base + STATIC_PENDING_OFFSET;
+        ws.lane_sums = reinterpret_cast<float4*>(base + STATIC_LANE_SUMS_OFFSET);
+        ws.pool = reinterpret_cast<uint4*>(base + STATIC_POOL_OFFSET);
+    } else if (L.compact) {
+        st = ensure_workspace(ctx, L);   // allocates only when this render needs more than any before it
+        if (st != RT_OK) return st;
+        ws = ctx->ws;
+    }
+    if (rays || L.compact) {
+        // the fill count of the pool must start at zero; everything else in the workspace is written before it is read
+        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays, L.compact ? ws.pool_count : nullptr);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
+    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, stream));
+    if (!L.compact) {
+        RT_HIP_CHECK(ctx, launch(ctx, L, 0, d_pixels, d_radiance, rays, ws, stream));
+    } else {
+        RT_HIP_CHECK(ctx, launch(ctx, L, 1, d_pixels, d_radiance, rays, ws, stream));
+        RT_HIP_CHECK(ctx, launch(ctx, L, 2, d_pixels, d_radiance, rays, ws, stream));
+        const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
+        hipLaunchKernelGGL(rt::pixel_combine_kernel, dim3((uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS)),
+                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ws.lane_sums, ws.pending, d_pixels, d_radiance);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));
+    ctx->timed = timed;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -412,6 +495,22 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
         return RT_ERR_HIP;
     }
     (void)hipFree(d_warm);
+    // This device's copy of the fixed workspace (see `scratch`): looked up once per device, with that device current.
+    {
+        static std::mutex lookup_mutex;
+        static std::vector<unsigned char*> per_device;
+        std::lock_guard<std::mutex> lock(lookup_mutex);
+        if (per_device.size() < (size_t)count) per_device.resize((size_t)count, nullptr);
+        if (!per_device[device_ordinal]) {
+            void* address = nullptr;
+            if (hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)) != hipSuccess || !address) {
+                rt_destroy(ctx);
+                return RT_ERR_HIP;
+            }
+            per_device[device_ordinal] = static_cast<unsigned char*>(address);
+        }
+        ctx->static_scratch = per_device[device_ordinal];
+    }
     *out_context = ctx;
     return RT_OK;
 }
@@ -551,39 +650,12 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
 
 rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
                            uint64_t* d_rays, void* hip_stream) {
-    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
-    if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
-    Launch L;
-    rt_status st = validate_and_plan(ctx, params, &L);
-    if (st != RT_OK) return st;
-    if ((params->flags & RT_FLAG_ACCUMULATE) && (!d_radiance || d_pixels))
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_ACCUMULATE needs a radiance buffer and no pixel buffer");
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    unsigned long long* rays = reinterpret_cast<unsigned long long*>(d_rays);
-    if (L.compact) {
-        st = ensure_workspace(ctx, L);   // allocates only when this render needs more than any before it
-        if (st != RT_OK) return st;
-    }
-    if (rays || L.compact) {
-        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays, L.compact ? ctx->ws.pool_count : nullptr);
-        RT_HIP_CHECK(ctx, hipGetLastError());
-    }
-    const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
-    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, stream));
-    if (!L.compact) {
-        RT_HIP_CHECK(ctx, launch(ctx, L, 0, d_pixels, d_radiance, rays, ctx->ws, stream));
-    } else {
-        RT_HIP_CHECK(ctx, launch(ctx, L, 1, d_pixels, d_radiance, rays, ctx->ws, stream));
-        RT_HIP_CHECK(ctx, launch(ctx, L, 2, d_pixels, d_radiance, rays, ctx->ws, stream));
-        const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
-        hipLaunchKernelGGL(rt::pixel_combine_kernel, dim3((uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS)),
-                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ctx->ws.lane_sums, ctx->ws.pending, d_pixels, d_radiance);
-        RT_HIP_CHECK(ctx, hipGetLastError());
-    }
-    if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));
-    ctx->timed = timed;
-    return RT_OK;
+    return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, false);
+}
+
+rt_status rt_render_device_noalloc(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
+                                   uint64_t* d_rays, void* hip_stream) {
+    return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, true);
 }
 
 rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
