@@ -112,7 +112,10 @@ enum {  /* rt_render_params.flags */
      * finished hands its last, nearly complete streams to a second launch that packs them densely; a third
      * small kernel adds the per-stream sums of each pixel.  Same results bit for bit, fewer idle lanes.  Uses
      * a workspace owned by the context (16 B per stream + 40 B per lane), allocated by the first render that
-     * needs it or by rt_reserve: that call allocates, later ones do not. */
+     * needs it or by rt_reserve: that call allocates, later ones do not.  The workspace is per context: at most
+     * ONE compacted render of a context may be in flight at a time (two of them enqueued on different streams,
+     * or two captured graphs replayed concurrently, race on it and give wrong pixels); use one context per
+     * concurrent stream. */
     RT_FLAG_COMPACT_TAILS = 4u,
     /* Progressive rendering: radiance (which must be given; pixels must be NULL) is not overwritten but added
      * to: radiance[i] = radiance[i] + this render's sample sum, as a host loop `sum += pass` would do.  With
@@ -224,9 +227,22 @@ rt_status rt_load_accumulator(rt_context* context, const rt_render_params* param
  * replacement of the reference's worker threads, main.cpp:450-461, at GPU granularity) and the
  * bands are interleaved back into full-size outputs: (row_end-row_begin) x width pixels / radiance,
  * *rays = sum over GPUs.  Every context must hold the same world.  params->band_* are ignored.
- * The same context may appear more than once (its shares are then rendered one after another). */
+ * The same context may appear more than once (its shares are then rendered one after another), except with
+ * RT_FLAG_OUTPUT_SUM / RT_FLAG_ACCUMULATE: a context keeps one running sum, so that is refused. */
 rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
                           uint32_t* pixels, float* radiance, uint64_t* rays);
+
+/* Adds `part_count` (1..64) radiance sums of `value_count` floats each, part k starting at
+ * d_sums + k * part_stride, into d_out (which may be part 0) in a FIXED order: neighbouring parts first
+ * (0+1, 2+3, ...), then neighbouring pairs, left operand first - the order in which the render kernel adds
+ * the lanes_per_pixel streams of a pixel.  This is how the sample-sharded multi-GPU mode composes its
+ * image: the per-GPU sums (RT_FLAG_OUTPUT_SUM renders with batch_offset = gpu * lanes_per_pixel) are
+ * gathered and added here, so that N = 2^k GPUs give the image of one GPU rendering N * lanes_per_pixel
+ * streams per pixel, bit for bit, whatever order a transport's reduction would have used.  The reference
+ * has one process and no counterpart; its row sums are serial (main.cpp:379-392).  Device pointers,
+ * asynchronous on hip_stream. */
+rt_status rt_combine_device(rt_context* context, const float* d_sums, uint32_t part_count, uint64_t part_stride,
+                            uint64_t value_count, float* d_out, void* hip_stream);
 
 /* Tonemap + pack of an accumulated radiance sum (sum over passes or GPUs of
  * RT_FLAG_OUTPUT_SUM renders): pixels[i] = pack(sum[i] / total_samples), the

@@ -14,6 +14,18 @@
 
 #include "rt_oracle_internal.h"
 
+/* Event counters (see rto_statistics): per thread while rendering, folded into `last_statistics` when a
+ * worker of rto_render ends. */
+static __thread rto_statistics tls_stats;
+static rto_statistics last_statistics;
+static pthread_mutex_t statistics_mutex = PTHREAD_MUTEX_INITIALIZER;
+
+void rto_last_statistics(rto_statistics* out) {
+    pthread_mutex_lock(&statistics_mutex);
+    *out = last_statistics;
+    pthread_mutex_unlock(&statistics_mutex);
+}
+
 /* ---------------------------------------------------------------- vectors */
 static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -262,11 +274,13 @@ static int intersect_scalar(const rto_scene* s, float min_hit, float plane_tol, 
         float disc = b * b - 4 * a * cc;
         float denom = 2 * a;
         if (disc > 0) {
+            ++tls_stats.sphere_roots;
             float tp = (-b + sqrtf(disc)) / denom;
             float tn = (-b - sqrtf(disc)) / denom;
             float hit = tp;
             if (tn > min_hit && tn < tp) hit = tn;
             if (hit > min_hit && hit < best_t) {
+                ++tls_stats.sphere_updates;
                 best_t = hit;
                 best_mat = sp->material_index;
                 v3 hp = vadd(o, vscale(d, hit));
@@ -287,6 +301,7 @@ static int intersect_scalar(const rto_scene* s, float min_hit, float plane_tol, 
         float hy = lo[1] + ld[1] * t;
         int hit = hx <= 1.0f && hx >= -1.0f && hy <= 1.0f && hy >= -1.0f;
         if (hit && t < best_t && t > min_hit) {
+            ++tls_stats.rectangle_updates;
             best_t = t;
             best_mat = r->material_index;
             v3 n = from3(r->normal);
@@ -349,12 +364,14 @@ static int intersect_wide(const rto_scene* s, int ieee_rsqrt, float min_hit, flo
             float disc = fmaf(b, b, -(4.0f * a * c));
             float denom = 2.0f * a;
             if (!(disc > 0.0f)) continue;
+            ++tls_stats.sphere_roots;
             float root = sqrtf(disc);
             float tp = (-b + root) / denom;
             float tn = (-b - root) / denom;
             float hit = tp;
             if (tn > min_hit && tn < tp) hit = tn;
             if (hit > min_hit && hit < lane_t[j]) {
+                ++tls_stats.sphere_updates;
                 lane_t[j] = hit;
                 lane_mat[j] = blk[4 * LANES + j];
                 float hx = fmaf(d.x, hit, o.x), hy = fmaf(d.y, hit, o.y), hz = fmaf(d.z, hit, o.z);
@@ -382,6 +399,7 @@ static int intersect_wide(const rto_scene* s, int ieee_rsqrt, float min_hit, flo
             float hy = lo[1] + ld[1] * t;
             int hit = hx <= 1.0f && hx >= -1.0f && hy <= 1.0f && hy >= -1.0f;
             if (hit && t < lane_t[j] && t > min_hit) {
+                ++tls_stats.rectangle_updates;
                 lane_t[j] = t;
                 lane_mat[j] = blk[19 * LANES + j];
                 float nx = blk[16 * LANES + j], ny = blk[17 * LANES + j], nz = blk[18 * LANES + j];
@@ -434,9 +452,11 @@ static uint32_t raytrace_world(const rto_scene* s, const rto_params* p, v3 origi
         float t; uint32_t mat_index; v3 n;
         int hit = intersect(s, (int)p->intersect_mode, p->min_hit_distance, p->plane_tolerance, ro, rd, &t, &mat_index, &n);
         ++bounces;
+        ++tls_stats.rays;
         const rto_material* mat = &s->materials[mat_index];
         v3 emit = from3(mat->emit_color);
         if (hit) {
+            ++tls_stats.hits;
             result = vadd(result, vmul(attenuation, emit));
             attenuation = vmul(attenuation, from3(mat->color));
             ro = vadd(ro, vscale(rd, t));
@@ -455,6 +475,7 @@ static uint32_t raytrace_world(const rto_scene* s, const rto_params* p, v3 origi
             v3 refracted = reflected;
             if (mat->refractive_index != 0.0f) {
                 if (refract(rd, n, mat->refractive_index, &refracted)) {
+                    ++tls_stats.refracting_hits;
                     refracted = vnormalize(refracted);
                     fresnel = schlick(rd, n, mat->refractive_index);
                 }
@@ -513,6 +534,7 @@ static inline uint32_t trace_sample(const rto_scene* s, const rto_params* p, con
     v3 film_pos = vadd(vadd(f->film_center, vscale(vscale(f->cam_x, off_x), f->half_w)),
                        vscale(vscale(f->cam_y, f->half_h), off_y));
     v3 dir = vnormalize(vsub(film_pos, f->cam_pos));
+    ++tls_stats.samples;
     v3 c;
     uint32_t b = raytrace_world(s, p, f->cam_pos, dir, state, &c);
     *color = vadd(*color, c);
@@ -607,7 +629,17 @@ static int raytrace_work(work_queue* q) { /* main.cpp:336-343, 397-399 */
 }
 
 static void* thread_proc(void* arg) {
+    memset(&tls_stats, 0, sizeof tls_stats);
     while (raytrace_work((work_queue*)arg)) {}
+    pthread_mutex_lock(&statistics_mutex);
+    last_statistics.rays += tls_stats.rays;
+    last_statistics.samples += tls_stats.samples;
+    last_statistics.hits += tls_stats.hits;
+    last_statistics.refracting_hits += tls_stats.refracting_hits;
+    last_statistics.sphere_roots += tls_stats.sphere_roots;
+    last_statistics.sphere_updates += tls_stats.sphere_updates;
+    last_statistics.rectangle_updates += tls_stats.rectangle_updates;
+    pthread_mutex_unlock(&statistics_mutex);
     return NULL;
 }
 
@@ -629,6 +661,9 @@ int rto_render(const rto_scene* scene, const rto_params* p, int threads,
     q.order_count = (q.local_rows + q.rows_per_order - 1) / q.rows_per_order;
     q.pixels = pixels; q.radiance = radiance;
 
+    pthread_mutex_lock(&statistics_mutex);
+    memset(&last_statistics, 0, sizeof last_statistics);
+    pthread_mutex_unlock(&statistics_mutex);
     if (threads < 1) threads = 1;
     pthread_t* pool = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     for (int i = 1; i < threads; ++i) pthread_create(&pool[i], NULL, thread_proc, &q);

@@ -101,6 +101,21 @@ uint32_t rto_raytrace_world(const rto_scene* scene, const rto_params* p,
 int rto_render(const rto_scene* scene, const rto_params* p, int threads,
                uint32_t* pixels, float* radiance, uint64_t* rays);
 
+/* Event counts of the last rto_render (summed over its threads) for the algorithmic flop count of a
+ * configuration: the terms of F_ray = 17 P + 20 S + 11 S_disc + 18 S_upd + 45 R + 6 R_upd + 62 [hit]
+ * + 60 [refracting hit] + 40 / (rays per sample).  Counted by the lane-by-lane and scalar intersection
+ * routines (RTO_INTERSECT_WIDE8, _WIDE8_IEEE, _SCALAR); the AVX2 form counts rays and samples only. */
+typedef struct {
+    uint64_t rays;             /* world intersections (main.cpp:277-278) */
+    uint64_t samples;          /* primary rays (main.cpp:379-390) */
+    uint64_t hits;             /* intersections that hit something */
+    uint64_t refracting_hits;  /* hits on a dielectric whose Refract succeeded (math_util.h:52-79) */
+    uint64_t sphere_roots;     /* (ray, sphere) pairs with disc > 0: roots evaluated (main.cpp:73-77) */
+    uint64_t sphere_updates;   /* closest-hit updates by a sphere (main.cpp:78-90) */
+    uint64_t rectangle_updates;/* closest-hit updates by a rectangle (main.cpp:121-127) */
+} rto_statistics;
+void rto_last_statistics(rto_statistics* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTS = (
     "rt_abi_version", "rt_status_string", "rt_create", "rt_destroy", "rt_error_string",
     "rt_get_device_info", "rt_default_params", "rt_local_row_count", "rt_global_row",
     "rt_upload_world", "rt_reserve", "rt_load_accumulator", "rt_render", "rt_render_device", "rt_render_device_noalloc",
-    "rt_render_multi", "rt_resolve_device", "rt_resolve",
+    "rt_render_multi", "rt_combine_device", "rt_resolve_device", "rt_resolve",
     "rt_last_kernel_ms",
 )
 
@@ -124,6 +124,8 @@ def load_library() -> C.CDLL:
     L.rt_render_multi.restype = C.c_int
     L.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_uint64)]
+    L.rt_combine_device.restype = C.c_int
+    L.rt_combine_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.rt_resolve_device.restype = C.c_int
     L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_resolve.restype = C.c_int
@@ -244,6 +246,11 @@ class Context:
                               d_rays: int | None, stream: int | None = None):
         """render_device with the fixed per-GPU workspace: allocates nothing; refuses sizes the workspace cannot hold."""
         self._check(self._lib.rt_render_device_noalloc(self._h, C.byref(params), d_pixels, d_radiance, d_rays, stream))
+
+    def combine_device(self, d_sums: int, part_count: int, part_stride: int, value_count: int, d_out: int,
+                       stream: int | None = None):
+        """Fixed-order (pairwise tree) sum of part_count radiance sums, part k at d_sums + 4 * k * part_stride."""
+        self._check(self._lib.rt_combine_device(self._h, d_sums, part_count, part_stride, value_count, d_out, stream))
 
     def resolve_device(self, d_sum: int, pixel_count: int, total_samples: int, d_pixels: int | None,
                        d_mean: int | None, stream: int | None = None):

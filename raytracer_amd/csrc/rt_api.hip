@@ -45,7 +45,8 @@ struct rt_context {
     // buffers behind rt_render (host outputs); grow-only
     uint32_t* d_pixels = nullptr;
     float* d_radiance = nullptr;
-    size_t pixel_capacity = 0, radiance_capacity = 0;
+    float* d_resolve_sum = nullptr;  // rt_resolve's copy of the caller's host-resident sum
+    size_t pixel_capacity = 0, radiance_capacity = 0, resolve_capacity = 0;
     // running sum of RT_FLAG_ACCUMULATE renders through rt_render: d_radiance, valid for the rows of this key
     bool accumulator_valid = false;
     uint32_t accumulator_key[6] = {0, 0, 0, 0, 0, 0};
@@ -185,6 +186,9 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     out->block_threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
     uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
+    // The kernels index lanes and streams (pixel * lanes_per_pixel + batch) with 32-bit integers.
+    if (blocks * out->block_threads > 0xFFFFFFFFull || (uint64_t)k.local_rows * k.width * k.lanes_per_pixel > 0xFFFFFFFFull)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rows x width x lanes_per_pixel must stay below 2^32");
     out->blocks = (uint32_t)blocks;
     if (out->compact) {
         // A stage-1 wave hands over at most pool_threshold streams, so waves * threshold entries always suffice.
@@ -376,6 +380,19 @@ rt_status render_to_host(rt_context* ctx, const rt_render_params* params, uint32
     return RT_OK;
 }
 
+// No exception may cross the C ABI: the entry points that touch std::vector, std::string or std::thread run
+// their bodies through this.
+template <typename Body>
+rt_status guarded(Body&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return RT_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return RT_ERR_HIP;
+    }
+}
+
 // Layout of the fixed per-GPU workspace behind rt_render_device_noalloc (STATIC_SCRATCH_BYTES in all):
 //   [0, 256)                     fill count of the pool
 //   [256, 256 + 1 MiB)           one pending flag per pixel          -> at most 2^20 pixels
@@ -522,6 +539,7 @@ void rt_destroy(rt_context* ctx) {
         if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
     if (ctx->d_pixels) (void)hipFree(ctx->d_pixels);
     if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
+    if (ctx->d_resolve_sum) (void)hipFree(ctx->d_resolve_sum);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
     if (ctx->ws.lane_sums) (void)hipFree(ctx->ws.lane_sums);
@@ -588,7 +606,7 @@ uint32_t rt_global_row(const rt_render_params* p, uint32_t local) {
     return p->row_begin + (band * p->band_count + p->band_index) * p->band_rows + within;
 }
 
-rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
+static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!w || !w->camera || !w->materials || w->material_count == 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "world needs a camera and at least the sky material");
@@ -630,11 +648,22 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
         if ((size_t)images[i][rt::H_LDS_WORDS] * 4 > lds_limit)
             return fail(ctx, RT_ERR_TOO_LARGE, "planes, rectangles and materials take %zu bytes, the LDS of one workgroup holds %zu",
                         (size_t)images[i][rt::H_LDS_WORDS] * 4, lds_limit);
+    // Both new images are allocated and filled before the context is touched, so a failure leaves the
+    // previous world in place and usable.
+    uint4* fresh[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipMalloc(&fresh[i], images[i].size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(fresh[i], images[i].data(), images[i].size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            for (int j = 0; j <= i; ++j)
+                if (fresh[j]) (void)hipFree(fresh[j]);
+            return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "rt_upload_world: %s", hipGetErrorString(e));
+        }
+    }
     RT_HIP_CHECK(ctx, hipDeviceSynchronize());   // no render may still read the old images
     for (int i = 0; i < 2; ++i) {
-        if (ctx->d_image[i]) { RT_HIP_CHECK(ctx, hipFree(ctx->d_image[i])); ctx->d_image[i] = nullptr; }
-        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_image[i], images[i].size() * 4));
-        RT_HIP_CHECK(ctx, hipMemcpy(ctx->d_image[i], images[i].data(), images[i].size() * 4, hipMemcpyHostToDevice));
+        if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
+        ctx->d_image[i] = fresh[i];
         ctx->image_words[i] = (uint32_t)images[i].size();
     }
     ctx->camera = *w->camera;
@@ -650,15 +679,15 @@ rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
 
 rt_status rt_render_device(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
                            uint64_t* d_rays, void* hip_stream) {
-    return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, false);
+    return guarded([&] { return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, false); });
 }
 
 rt_status rt_render_device_noalloc(rt_context* ctx, const rt_render_params* params, uint32_t* d_pixels, float* d_radiance,
                                    uint64_t* d_rays, void* hip_stream) {
-    return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, true);
+    return guarded([&] { return render_device(ctx, params, d_pixels, d_radiance, d_rays, hip_stream, true); });
 }
 
-rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
+static rt_status reserve_impl(rt_context* ctx, const rt_render_params* params) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
     Launch L;
@@ -668,7 +697,7 @@ rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
     return L.compact ? ensure_workspace(ctx, L) : RT_OK;
 }
 
-rt_status rt_load_accumulator(rt_context* ctx, const rt_render_params* params, const float* radiance_sum) {
+static rt_status load_accumulator_impl(rt_context* ctx, const rt_render_params* params, const float* radiance_sum) {
     if (!ctx || !radiance_sum) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_world) return fail(ctx, RT_ERR_NO_WORLD, "rt_upload_world has not been called");
     Launch L;
@@ -687,16 +716,35 @@ rt_status rt_load_accumulator(rt_context* ctx, const rt_render_params* params, c
 }
 
 rt_status rt_render(rt_context* ctx, const rt_render_params* params, uint32_t* pixels, float* radiance, uint64_t* rays) {
-    return render_to_host(ctx, params, pixels, radiance, rays, false, 0);
+    return guarded([&] { return render_to_host(ctx, params, pixels, radiance, rays, false, 0); });
 }
 
-rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
-                          uint32_t* pixels, float* radiance, uint64_t* rays) {
+rt_status rt_upload_world(rt_context* ctx, const rt_world* w) {
+    return guarded([&] { return upload_world_impl(ctx, w); });
+}
+
+rt_status rt_reserve(rt_context* ctx, const rt_render_params* params) {
+    return guarded([&] { return reserve_impl(ctx, params); });
+}
+
+rt_status rt_load_accumulator(rt_context* ctx, const rt_render_params* params, const float* radiance_sum) {
+    return guarded([&] { return load_accumulator_impl(ctx, params, radiance_sum); });
+}
+
+static rt_status render_multi_impl(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
+                                   uint32_t* pixels, float* radiance, uint64_t* rays) {
     if (!contexts || context_count == 0 || !params) return RT_ERR_INVALID_ARGUMENT;
     for (uint32_t i = 0; i < context_count; ++i)
         if (!contexts[i]) return RT_ERR_INVALID_ARGUMENT;
     if (params->struct_size != sizeof(rt_render_params) || params->row_end <= params->row_begin || params->width == 0)
         return fail(contexts[0], RT_ERR_INVALID_ARGUMENT, "rt_render_multi: bad struct_size, width or row range");
+    // A context keeps ONE running sum: listed twice, its second share would overwrite the first one's.
+    if (params->flags & (RT_FLAG_OUTPUT_SUM | RT_FLAG_ACCUMULATE))
+        for (uint32_t i = 0; i < context_count; ++i)
+            for (uint32_t j = 0; j < i; ++j)
+                if (contexts[i] == contexts[j])
+                    return fail(contexts[0], RT_ERR_INVALID_ARGUMENT,
+                                "rt_render_multi: a context listed more than once cannot render with RT_FLAG_OUTPUT_SUM or RT_FLAG_ACCUMULATE");
     std::vector<rt_render_params> shard_params(context_count, *params);
     std::vector<uint64_t> shard_rays(context_count, 0);
     std::vector<rt_status> status(context_count, RT_OK);
@@ -739,6 +787,20 @@ rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, c
     return RT_OK;
 }
 
+rt_status rt_combine_device(rt_context* ctx, const float* d_sums, uint32_t part_count, uint64_t part_stride,
+                            uint64_t value_count, float* d_out, void* hip_stream) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!d_sums || !d_out || part_count == 0 || part_count > 64 || value_count == 0 || value_count > (1ull << 35) ||
+        (part_count > 1 && part_stride < value_count))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_combine_device: bad pointers, part count (1..64), stride or value count");
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t blocks = (uint32_t)((value_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS);
+    hipLaunchKernelGGL(rt::combine_kernel, dim3(blocks), dim3(rt::BLOCK_THREADS), 0, static_cast<hipStream_t>(hip_stream), d_sums,
+                       part_count, part_stride, value_count, d_out);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 rt_status rt_resolve_device(rt_context* ctx, const float* d_sum, uint64_t pixel_count, uint32_t total_samples,
                             uint32_t* d_pixels, float* d_mean, void* hip_stream) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
@@ -752,8 +814,8 @@ rt_status rt_resolve_device(rt_context* ctx, const float* d_sum, uint64_t pixel_
     return RT_OK;
 }
 
-rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_count, uint32_t total_samples,
-                     uint32_t* pixels, float* radiance_mean) {
+static rt_status resolve_impl(rt_context* ctx, const float* radiance_sum, uint64_t pixel_count, uint32_t total_samples,
+                               uint32_t* pixels, float* radiance_mean) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!radiance_sum || pixel_count == 0 || total_samples == 0 || pixel_count > (1ull << 33))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve: bad sum pointer, pixel count or sample count");
@@ -761,9 +823,14 @@ rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_
     rt_status st = ensure_output_capacity(ctx, (size_t)pixel_count, pixels != nullptr, radiance_mean != nullptr);
     if (radiance_mean) ctx->accumulator_valid = false;   // the mean is staged in the radiance buffer
     if (st != RT_OK) return st;
-    float* d_sum = nullptr;
     const size_t sum_bytes = (size_t)pixel_count * 3 * sizeof(float);
-    RT_HIP_CHECK(ctx, hipMalloc(&d_sum, sum_bytes));
+    if ((size_t)pixel_count > ctx->resolve_capacity) {   // grow-only buffer of the context: repeated resolves allocate nothing
+        if (ctx->d_resolve_sum) { RT_HIP_CHECK(ctx, hipFree(ctx->d_resolve_sum)); ctx->d_resolve_sum = nullptr; }
+        ctx->resolve_capacity = 0;
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->d_resolve_sum, sum_bytes));
+        ctx->resolve_capacity = (size_t)pixel_count;
+    }
+    float* d_sum = ctx->d_resolve_sum;
     hipError_t e = hipMemcpy(d_sum, radiance_sum, sum_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         st = rt_resolve_device(ctx, d_sum, pixel_count, total_samples, pixels ? ctx->d_pixels : nullptr,
@@ -774,10 +841,19 @@ rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_
         if (st == RT_OK && e == hipSuccess && radiance_mean)
             e = hipMemcpy(radiance_mean, ctx->d_radiance, sum_bytes, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d_sum);
     if (st != RT_OK) return st;
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_resolve: %s", hipGetErrorString(e));
     return RT_OK;
+}
+
+rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, const rt_render_params* params,
+                          uint32_t* pixels, float* radiance, uint64_t* rays) {
+    return guarded([&] { return render_multi_impl(contexts, context_count, params, pixels, radiance, rays); });
+}
+
+rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_count, uint32_t total_samples,
+                     uint32_t* pixels, float* radiance_mean) {
+    return guarded([&] { return resolve_impl(ctx, radiance_sum, pixel_count, total_samples, pixels, radiance_mean); });
 }
 
 rt_status rt_last_kernel_ms(rt_context* ctx, float* out_ms) {

@@ -817,6 +817,34 @@ __global__ __launch_bounds__(BLOCK_THREADS) void pixel_combine_kernel(KernelPara
     emit_pixel(p, tree_sum(lane_sums + i * p.lanes_per_pixel, p.lanes_per_pixel), i, pixels, radiance);
 }
 
+// Sum of `parts` radiance sums (one per GPU or per pass, `stride` floats apart) in the order of tree_sum:
+// neighbours first, then neighbouring pairs, left operand first; a count that is not a power of two
+// carries its odd block up unchanged.  For a power-of-two count this continues the per-pixel tree of the
+// render kernel, so N GPUs with B streams per pixel each give the sums of one GPU with N*B streams.
+__global__ __launch_bounds__(BLOCK_THREADS) void combine_kernel(const float* __restrict__ sums, uint32_t parts, uint64_t stride,
+                                                                uint64_t count, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    if (i >= count) return;
+    float partial[7];    // partial[l]: a completed block of 2^l parts waiting for its right neighbour (parts <= 64)
+    uint32_t occupied = 0;
+    float v = 0.0f;
+    for (uint32_t k = 0; k < parts; ++k) {
+        v = sums[(uint64_t)k * stride + i];
+        uint32_t level = 0;
+        for (; (k >> level) & 1u; ++level) v = partial[level] + v;
+        partial[level] = v;
+        occupied = (occupied & ~((1u << level) - 1u)) | (1u << level);
+    }
+    // leftover blocks of a count that is not a power of two: the smallest (rightmost) joins its left neighbour first
+    bool first = true;
+    for (uint32_t level = 0; level < 7; ++level) {
+        if (!((occupied >> level) & 1u)) continue;
+        v = first ? partial[level] : partial[level] + v;
+        first = false;
+    }
+    out[i] = v;
+}
+
 // Tonemap + pack of an accumulated sum (epilogue of main.cpp:393 on its own).
 __global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const float* __restrict__ sum, uint64_t pixel_count,
                                                                 float total_samples, uint32_t* __restrict__ pixels,

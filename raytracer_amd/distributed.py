@@ -8,8 +8,14 @@ exchange is assembling the result on rank 0:
            b mod N: the Cornell box is half black rows, so contiguous slabs would be uneven)
            and the packed rows are collected with ONE all_gather.
   samples  each rank renders every pixel with its own sample-batch indices
-           (batch_offset = rank * lanes_per_pixel) and the un-normalised radiance sums are
-           added onto rank 0 with ONE reduce(SUM), then tonemapped there.
+           (batch_offset = rank * lanes_per_pixel); the un-normalised radiance sums are
+           collected on rank 0 with ONE gather and added there in a FIXED pairwise tree over
+           the ranks (rank 0 + rank 1, rank 2 + rank 3, then the pairs, ...), then tonemapped.
+           A reduce(SUM) would add in whatever order the transport's ring or tree visits the
+           ranks; the fixed tree continues the kernel's own pairwise tree over the
+           lanes_per_pixel streams of a pixel, so for a power-of-two number of ranks the image
+           equals, bit for bit, the single-GPU render of all the batches
+           (lanes_per_pixel * world_size streams per pixel).
 
 The renderer itself is injected (`render` / `resolve` callables working on torch tensors),
 so the same composition runs on GPUs with the HIP library and, in the CPU tests, over gloo.
@@ -77,6 +83,7 @@ class RowShardedImage:
         # concatenation of the shards along rows; viewed as [rank, row, x]
         self._gathered_flat = torch.zeros((world_size * self.max_rows, params.width), dtype=torch.int32, device=device)
         self.gathered = self._gathered_flat.view(world_size, self.max_rows, params.width)
+        self._source_rows = None
 
     def gather(self):
         if self.world_size > 1:
@@ -84,22 +91,50 @@ class RowShardedImage:
         else:
             self.gathered[0].copy_(self.shard)
 
-    def assemble(self) -> torch.Tensor:
-        """Full image [rows, W] in global row order (call after gather)."""
-        total = self.all_params[0].row_end - self.all_params[0].row_begin
-        begin = self.all_params[0].row_begin
-        image = torch.zeros((total, self.width), dtype=torch.int32, device=self.gathered.device)
-        for r, p in enumerate(self.all_params):
-            rows = torch.tensor([g - begin for g in global_rows(p)], dtype=torch.long, device=self.gathered.device)
-            if len(rows):
-                image[rows] = self.gathered[r, :len(rows)]
-        return image
+    def assemble(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Full image [rows, W] in global row order (call after gather): one gather-by-row-index copy."""
+        if self._source_rows is None:
+            total = self.all_params[0].row_end - self.all_params[0].row_begin
+            begin = self.all_params[0].row_begin
+            source = torch.zeros(total, dtype=torch.long)
+            for r, p in enumerate(self.all_params):
+                for local, g in enumerate(global_rows(p)):
+                    source[g - begin] = r * self.max_rows + local      # row of the concatenated shards
+            self._source_rows = source.to(self._gathered_flat.device)
+        if out is None:
+            return self._gathered_flat.index_select(0, self._source_rows)
+        return torch.index_select(self._gathered_flat, 0, self._source_rows, out=out)
 
 
-def reduce_radiance_sum(radiance_sum: torch.Tensor, world_size: int):
-    """Adds every rank's un-normalised radiance sum onto rank 0 (in place)."""
-    if world_size > 1:
-        dist.reduce(radiance_sum, dst=0, op=dist.ReduceOp.SUM)
+class GatheredSums:
+    """Receive buffer of the `samples` mode on rank 0: [world_size, rows, W, 3] float32, one slice per rank."""
+
+    def __init__(self, like: torch.Tensor, rank: int, world_size: int):
+        self.rank, self.world_size = rank, world_size
+        self.parts = torch.zeros((world_size,) + tuple(like.shape), dtype=like.dtype, device=like.device) if rank == 0 else None
+
+    def gather(self, radiance_sum: torch.Tensor):
+        """Collects every rank's sum on rank 0 (one gather; nothing is added in transit)."""
+        if self.world_size == 1:
+            self.parts[0].copy_(radiance_sum)
+        elif self.rank == 0:
+            dist.gather(radiance_sum, gather_list=[self.parts[r] for r in range(self.world_size)], dst=0)
+        else:
+            dist.gather(radiance_sum, gather_list=None, dst=0)
+
+
+def tree_order_sum(parts: torch.Tensor) -> torch.Tensor:
+    """Sum over the first axis in the fixed pairwise order of the kernel's per-pixel tree: neighbours
+    first (0+1, 2+3, ...), then neighbouring pairs, left operand first; a count that is not a power of
+    two carries its odd block up unchanged.  Element-wise float32 additions only, so the result does not
+    depend on who computes it."""
+    level = [parts[i] for i in range(parts.shape[0])]
+    while len(level) > 1:
+        nxt = [level[i] + level[i + 1] for i in range(0, len(level) - 1, 2)]
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
 
 
 def sum_rays(rays: torch.Tensor, world_size: int) -> torch.Tensor:
@@ -119,13 +154,16 @@ def render_rows(render: Callable, params, rank: int, world_size: int, device) ->
 
 
 def render_samples(render: Callable, resolve: Callable, params, rank: int, world_size: int, device,
-                   output_sum_flag: int):
+                   output_sum_flag: int, combine: Callable = tree_order_sum):
     """samples mode in one call.  `render(params, radiance_sum) -> rays` fills [H, W, 3] float32;
-    `resolve(radiance_sum, total_spp) -> pixels` runs on rank 0 only.  Returns (pixels or None, rays)."""
+    `combine(parts [N, H, W, 3]) -> sum` adds the ranks' sums in the fixed tree order and
+    `resolve(radiance_sum, total_spp) -> pixels` tonemaps; both run on rank 0 only.
+    Returns (pixels or None, rays)."""
     p = batch_params(params, rank, world_size, output_sum_flag)
     rows = p.row_end - p.row_begin
     radiance_sum = torch.zeros((rows, p.width, 3), dtype=torch.float32, device=device)
     rays = render(p, radiance_sum)
-    reduce_radiance_sum(radiance_sum, world_size)
-    pixels = resolve(radiance_sum, p.samples_per_pixel * world_size) if rank == 0 else None
+    gathered = GatheredSums(radiance_sum, rank, world_size)
+    gathered.gather(radiance_sum)
+    pixels = resolve(combine(gathered.parts), p.samples_per_pixel * world_size) if rank == 0 else None
     return pixels, rays

@@ -1,6 +1,8 @@
-"""The multi-rank composition (raytracer_amd/distributed.py) on two CPU processes over gloo,
-with the oracle standing in for the GPU renderer: sharded renders must reassemble into exactly
-the single-process image."""
+"""The multi-rank composition (raytracer_amd/distributed.py) on two and on four CPU processes over
+gloo, with the oracle standing in for the GPU renderer: sharded renders must reassemble into exactly
+the single-process image.  Four ranks matter for the sample-sharded mode: with two, a + b is the same
+in any order; with four, only the fixed pairwise tree ((0+1)+(2+3)) reproduces the single render of
+all the batches, whereas a ring reduction (((0+1)+2)+3) would not."""
 import ctypes as C
 import os
 import socket
@@ -53,7 +55,10 @@ def _worker(rank, world_size, port, out_dir):
             radiance_sum.copy_(torch.from_numpy(rad))
             return rays
 
+        combined = {}
+
         def resolve(radiance_sum, total_spp):
+            combined["sum"] = radiance_sum.numpy().copy()
             mean = (radiance_sum / np.float32(total_spp)).numpy()
             return np.array([O.lib().rto_pack_srgb(np.ascontiguousarray(px).ctypes.data_as(C.c_void_p))
                              for px in mean.reshape(-1, 3)], dtype=np.uint32).reshape(mean.shape[:2])
@@ -62,13 +67,13 @@ def _worker(rank, world_size, port, out_dir):
         stotal = D.sum_rays(torch.tensor([srays], dtype=torch.int64), world_size)
         if rank == 0:
             np.savez(os.path.join(out_dir, "out.npz"), rows_image=full.numpy().view(np.uint32), rows_rays=total.numpy(),
-                     sample_pixels=pixels, sample_rays=stotal.numpy())
+                     sample_pixels=pixels, sample_rays=stotal.numpy(), sample_sum=combined["sum"])
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_reassemble_the_single_process_image(tmp_path):
-    world_size = 2
+@pytest.mark.parametrize("world_size", [2, 4])
+def test_ranks_reassemble_the_single_process_image(tmp_path, world_size):
     mp.spawn(_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
     out = np.load(tmp_path / "out.npz")
     scene = O.OracleScene(read_scene(os.path.join(GOLDEN, "cornell.rtsc")))
@@ -77,10 +82,25 @@ def test_two_ranks_reassemble_the_single_process_image(tmp_path):
     pix, _, rays = scene.render(O.default_params(40, 27, 8, rng_mode=O.PIXEL, lanes_per_pixel=2))
     assert np.array_equal(out["rows_image"], pix) and int(out["rows_rays"][0]) == rays
 
-    # samples mode: two ranks x 8 spp (2 batches each) == one render of 16 spp with 4 batches
-    pix16, _, rays16 = scene.render(O.default_params(40, 27, 16, rng_mode=O.PIXEL, lanes_per_pixel=4))
-    assert int(out["sample_rays"][0]) == rays16
-    assert np.array_equal(out["sample_pixels"], pix16)
+    # samples mode: N ranks x 8 spp (2 batches each) == one render of 8N spp with 2N batches, bit for bit
+    pix_all, rad_all, rays_all = scene.render(O.default_params(40, 27, 8 * world_size, rng_mode=O.PIXEL,
+                                                               lanes_per_pixel=2 * world_size, output_sum=1))
+    assert int(out["sample_rays"][0]) == rays_all
+    assert np.array_equal(out["sample_sum"].view(np.uint32), rad_all.view(np.uint32))
+    assert np.array_equal(out["sample_pixels"], pix_all)
+
+
+def test_tree_order_sum_is_the_kernel_tree_and_not_a_ring():
+    """tree_order_sum adds ((0+1)+(2+3)); values chosen so that the ring order (((0+1)+2)+3) rounds differently."""
+    parts = torch.tensor([[1.0], [2.0 ** -24], [2.0 ** -24], [2.0 ** -24]], dtype=torch.float32)
+    tree = D.tree_order_sum(parts)
+    ring = ((parts[0] + parts[1]) + parts[2]) + parts[3]
+    expected = (parts[0] + parts[1]) + (parts[2] + parts[3])
+    assert torch.equal(tree, expected) and not torch.equal(tree, ring)
+    # counts that are not a power of two carry the odd block up: (0+1)+2, ((0+1)+(2+3))+4
+    five = torch.arange(5, dtype=torch.float32).reshape(5, 1) * 0.1
+    assert torch.equal(D.tree_order_sum(five[:3]), (five[0] + five[1]) + five[2])
+    assert torch.equal(D.tree_order_sum(five), ((five[0] + five[1]) + (five[2] + five[3])) + five[4])
 
 
 def test_band_helpers_match_the_c_abi():

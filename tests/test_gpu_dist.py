@@ -1,4 +1,4 @@
-"""Two processes, both rendering with the HIP library (here on the same GPU), composed by
+"""Two and four processes, all rendering with the HIP library (here on the same GPU), composed by
 raytracer_amd/distributed.py over gloo with host-side shards: everything of the multi-GPU path
 except the RCCL transport itself, which needs more than one GPU."""
 import os
@@ -62,17 +62,19 @@ def _worker(rank, world_size, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_processes_compose_the_single_gpu_image(tmp_path):
+@pytest.mark.parametrize("world_size", [2, 4])
+def test_processes_compose_the_single_gpu_image(tmp_path, world_size):
     from raytracer_amd import binding as B
     from raytracer_amd.host_scene import build_scene
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
     out = np.load(tmp_path / "out.npz")
     ctx = B.Context(0)
     ctx.upload_world(build_scene("cornell"))
     pix, _, rays = ctx.render(B.default_params(120, 70, 16, lanes_per_pixel=4))
     assert np.array_equal(out["rows_image"], pix) and int(out["rows_rays"][0]) == rays
-    # two ranks x 16 spp with 4 batches each == one render of 32 spp with 8 batches
-    pix32, _, rays32 = ctx.render(B.default_params(120, 70, 32, lanes_per_pixel=8))
-    assert int(out["sample_rays"][0]) == rays32
-    assert np.array_equal(out["sample_pixels"], pix32)
+    # N ranks x 16 spp with 4 batches each == one render of 16 N spp with 4 N batches (the ranks' sums are
+    # added in the fixed pairwise tree, which continues the kernel's tree over a pixel's streams)
+    pix_all, _, rays_all = ctx.render(B.default_params(120, 70, 16 * world_size, lanes_per_pixel=4 * world_size))
+    assert int(out["sample_rays"][0]) == rays_all
+    assert np.array_equal(out["sample_pixels"], pix_all)
     ctx.close()

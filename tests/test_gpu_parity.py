@@ -524,3 +524,96 @@ def test_random_scenes_bit_exact(ctx, seed):
     lanes = int(rng.choice([1, 2, 4]))
     check_against_oracle(ctx, scene, B.default_params(w, h, 64 * lanes, max_bounces=bounces, lanes_per_pixel=lanes,
                                                       flags=B.FLAG_COMPACT_TAILS))
+
+
+# ---------------------------------------------------------------- sums, passes and their composition, against the oracle
+
+def test_sum_output_batches_and_bands_against_the_oracle(ctx, cornell, spheres):
+    """The un-normalised sample sum (RT_FLAG_OUTPUT_SUM) with non-zero batch offsets, row bands and the
+    compacted launch sequence: each is the oracle's sum (rto_render with output_sum) bit for bit."""
+    check_against_oracle(ctx, cornell, B.default_params(64, 36, 16, lanes_per_pixel=4, flags=B.FLAG_OUTPUT_SUM))
+    check_against_oracle(ctx, cornell, B.default_params(64, 36, 16, lanes_per_pixel=4, batch_offset=12, flags=B.FLAG_OUTPUT_SUM))
+    check_against_oracle(ctx, spheres, B.default_params(80, 45, 8, lanes_per_pixel=2, batch_offset=1000, band_rows=8, band_index=2,
+                                                        band_count=3, flags=B.FLAG_OUTPUT_SUM))
+    check_against_oracle(ctx, build_scene("glass_spheres", 3), B.default_params(64, 36, 256, lanes_per_pixel=4, batch_offset=8,
+                                                                                max_bounces=32, flags=B.FLAG_OUTPUT_SUM | B.FLAG_COMPACT_TAILS))
+
+
+def test_accumulated_passes_against_the_oracle(ctx, cornell):
+    """A three-pass progressive render (sum render, then two RT_FLAG_ACCUMULATE renders with advancing batch
+    offsets) holds the float32 pass-order sum of three oracle sum renders; resolving it gives the pixels
+    of packing that sum / 48 (the running average of win32gpu/compute.glsl:382-391, kept as a sum)."""
+    ctx.upload_world(cornell)
+    osc = O.OracleScene(cornell)
+    lanes, spp = 4, 16
+    expected = None
+    rays_expected = 0
+    got = None
+    rays_got = 0
+    for k in range(3):
+        p = B.default_params(72, 40, spp, lanes_per_pixel=lanes, batch_offset=k * lanes,
+                             flags=B.FLAG_OUTPUT_SUM if k == 0 else B.FLAG_ACCUMULATE)
+        _, got, rays = ctx.render(p, want_pixels=False)
+        rays_got += rays
+        _, osum, orays = osc.render(oracle_params(B.default_params(72, 40, spp, lanes_per_pixel=lanes, batch_offset=k * lanes,
+                                                                   flags=B.FLAG_OUTPUT_SUM)))
+        expected = osum if expected is None else expected + osum      # float32, pass order
+        rays_expected += orays
+        assert np.array_equal(bits(got), bits(expected)), f"running sum differs after pass {k}"
+    assert rays_got == rays_expected
+    pixels, mean = ctx.resolve(got, 3 * spp)
+    omean = expected / np.float32(3 * spp)
+    assert np.array_equal(bits(mean), bits(omean))
+    opix = np.array([O.lib().rto_pack_srgb(np.ascontiguousarray(px).ctypes.data_as(C.c_void_p)) for px in omean.reshape(-1, 3)],
+                    dtype=np.uint32).reshape(pixels.shape)
+    assert_pixels_close(pixels, opix)
+    # the same chain through the device entry point with a caller-owned accumulator
+    import torch
+    dev = torch.device("cuda", 0)
+    acc = torch.zeros((40, 72, 3), dtype=torch.float32, device=dev)
+    rays = torch.zeros(3, dtype=torch.int64, device=dev)
+    for k in range(3):
+        p = B.default_params(72, 40, spp, lanes_per_pixel=lanes, batch_offset=k * lanes,
+                             flags=B.FLAG_OUTPUT_SUM if k == 0 else B.FLAG_ACCUMULATE)
+        ctx.render_device(p, None, acc.data_ptr(), rays.data_ptr() + 8 * k, None)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(expected)) and int(rays.sum()) == rays_expected
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 4, 5, 8])
+def test_combine_adds_in_the_fixed_tree_order(ctx, parts):
+    """rt_combine_device against the same tree written with element-wise float32 additions."""
+    import torch
+    from raytracer_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device="cpu").manual_seed(parts)
+    # magnitudes spread over 2^-20 .. 2^20, so that the order of the additions shows in the roundings
+    data = (torch.randn((parts, 4099), generator=gen) * torch.exp2(torch.randint(-20, 21, (parts, 4099), generator=gen).float())).to(dev)
+    out = torch.zeros(4099, dtype=torch.float32, device=dev)
+    ctx.combine_device(data.data_ptr(), parts, 4099, 4099, out.data_ptr(), None)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(out.cpu(), D.tree_order_sum(data.cpu()))
+    if parts == 4:   # and it is not what a ring would give
+        ring = ((data[0] + data[1]) + data[2]) + data[3]
+        assert not torch.equal(out, ring)
+
+
+def test_sample_sharded_composition_equals_one_render_of_all_batches(ctx, cornell):
+    """Four sample shards (what four GPUs render in the `samples` mode: batch_offset = rank * lanes) added by
+    rt_combine_device equal, bit for bit, the single render with 4 x lanes streams per pixel - and the oracle's."""
+    import torch
+    ctx.upload_world(cornell)
+    dev = torch.device("cuda", 0)
+    ranks, lanes, spp, w, h = 4, 4, 32, 96, 54
+    shards = torch.zeros((ranks, h, w, 3), dtype=torch.float32, device=dev)
+    rays = torch.zeros(ranks, dtype=torch.int64, device=dev)
+    for r in range(ranks):
+        p = B.default_params(w, h, spp, lanes_per_pixel=lanes, batch_offset=r * lanes, flags=B.FLAG_OUTPUT_SUM)
+        ctx.render_device(p, None, shards[r].data_ptr(), rays.data_ptr() + 8 * r, None)
+    total = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    ctx.combine_device(shards.data_ptr(), ranks, h * w * 3, h * w * 3, total.data_ptr(), None)
+    torch.cuda.synchronize(dev)
+    whole = B.default_params(w, h, spp * ranks, lanes_per_pixel=lanes * ranks, flags=B.FLAG_OUTPUT_SUM)
+    _, rad, whole_rays = check_against_oracle(ctx, cornell, whole)
+    assert int(rays.sum()) == whole_rays
+    assert np.array_equal(bits(total.cpu().numpy()), bits(rad))

@@ -148,12 +148,16 @@ def _known(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["cornell", "spheres"])
-def test_known_answers_320x180(golden_dir, scenes, name):
+def test_known_answers_320x180(golden_dir, scenes, name, tmp_path):
     k = _known(golden_dir)[f"{name}_320x180_64spp_strict"]
     pix, rad, rays = O.OracleScene(scenes[name]).render(O.default_params(320, 180, 64, intersect_mode=O.WIDE8_AVX2))
     assert rays == k["rays"]
     assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
     assert hashlib.sha256(pix.tobytes()).hexdigest() == k["pixels_sha256"]
+    # the host library's BMP writer on those pixels: the very file the reference wrote (image.cpp:11-40), byte for byte
+    from raytracer_amd.host_scene import write_bmp
+    write_bmp(tmp_path / "render.bmp", pix)
+    assert hashlib.md5((tmp_path / "render.bmp").read_bytes()).hexdigest() == k["bmp_md5"]
 
 
 @pytest.mark.slow
