@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--lanes-per-pixel", type=int, default=0)
     ap.add_argument("--no-compact", action="store_true", help="single-launch render (no tail compaction)")
     ap.add_argument("--shard", choices=("samples", "rows"), default="samples")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks that all render on GPU 0 and exchange through gloo + host copies: exercises the multi-rank path "
+                         "where only one GPU exists; its throughput means nothing")
     ap.add_argument("--cpu-spp", type=int, default=-1, help="spp of the bounded CPU-baseline sample (0 = skip, -1 = sized for ~10 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every online core, as the reference does)")
     return ap.parse_args()
@@ -153,11 +156,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)   # RCCL
 
     cfg = CONFIGS[args.config]
     W, H = args.width or cfg["width"], args.height or cfg["height"]
@@ -224,15 +232,35 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # Outside the timed region, N > 1: rank 0 renders the whole job alone and compares it with the image the
+    # ranks composed (pixels and ray count), so every multi-GPU line says whether the composition was exact.
+    composition = None
+    if distributed and rank == 0:
+        if rows_mode:
+            whole = base
+        else:
+            whole = B.default_params(W, H, spp * world_size, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes * world_size,
+                                     max_bounces=cfg["bounces"]) if B_lanes * world_size <= 64 else None
+        if whole is not None:
+            check_pixels = torch.zeros((H, W), dtype=torch.int32, device=device)
+            check_rays = torch.zeros(1, dtype=torch.int64, device=device)
+            whole.flags = 0
+            ctx.render_device(whole, check_pixels.data_ptr(), None, check_rays.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(device)
+            composition = {"pixels_identical_to_one_gpu_render": bool(torch.equal(check_pixels, pixels)),
+                           "one_gpu_rays": int(check_rays.item())}
+
     timed_rays = rays[args.warmup:].sum()
     kernel_ms = sum(starts[i].elapsed_time(stops[i]) for i in range(args.warmup, total)) / max(args.steps, 1)
     rank_rays_per_launch = int(timed_rays.item()) / max(args.steps, 1)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if args.rehearse_on_one_gpu:
+            t, timed_rays = t.cpu(), timed_rays.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(timed_rays, op=dist.ReduceOp.SUM)
-        km = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device=t.device)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kernel_ms = float(km.item())
     total_rays = int(timed_rays.item())
@@ -287,7 +315,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "rng_mode": "pixel", "lanes_per_pixel": B_lanes, "intersect_mode": "wide8",
                        "compact_tails": compacted, "max_bounces": cfg["bounces"], "rays_per_step": total_rays // max(args.steps, 1),
-                       "shard": args.shard if distributed else None,
+                       "shard": args.shard if distributed else None, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
                        "device": info.name.decode(), "compute_units": info.compute_units, "clock_mhz": info.clock_khz / 1e3},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -296,6 +324,9 @@ def main():
                          "kernel": "rt::render_kernel<WIDE8, PIXEL> stage 1 (dominant) + stage 2 + rt::pixel_combine_kernel, timed together" if compacted else
                                    "rt::render_kernel<WIDE8, PIXEL>"},
         }
+        if composition is not None:
+            composition["rays_identical"] = composition.pop("one_gpu_rays") == total_rays // max(args.steps, 1)
+            line["composition_check"] = composition
         if world_size == 1:
             line["cpu_baseline"] = cpu_baseline(W if args.config.startswith("cornell") else 1920, H if args.config.startswith("cornell") else 1080,
                                                 args.cpu_spp, args.cpu_threads)

@@ -31,6 +31,12 @@ import torch.distributed as dist
 BAND_ROWS = 8
 
 
+def _host_staged() -> bool:
+    """True when the process group cannot move device tensors itself (gloo): collectives then go through
+    host copies.  RCCL (backend "nccl") moves device memory directly over xGMI."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def band_params(params, rank: int, world_size: int, band_rows: int = BAND_ROWS):
     """Copy of `params` restricted to the row bands of `rank`."""
     p = copy.copy(params)
@@ -86,7 +92,11 @@ class RowShardedImage:
         self._source_rows = None
 
     def gather(self):
-        if self.world_size > 1:
+        if self.world_size > 1 and self.shard.is_cuda and _host_staged():
+            flat = torch.zeros(self._gathered_flat.shape, dtype=self.shard.dtype)
+            dist.all_gather_into_tensor(flat, self.shard.cpu())
+            self._gathered_flat.copy_(flat)
+        elif self.world_size > 1:
             dist.all_gather_into_tensor(self._gathered_flat, self.shard)
         else:
             self.gathered[0].copy_(self.shard)
@@ -117,6 +127,15 @@ class GatheredSums:
         """Collects every rank's sum on rank 0 (one gather; nothing is added in transit)."""
         if self.world_size == 1:
             self.parts[0].copy_(radiance_sum)
+        elif radiance_sum.is_cuda and _host_staged():
+            mine = radiance_sum.cpu()
+            if self.rank == 0:
+                received = [torch.zeros_like(mine) for _ in range(self.world_size)]
+                dist.gather(mine, gather_list=received, dst=0)
+                for r in range(self.world_size):
+                    self.parts[r].copy_(received[r])
+            else:
+                dist.gather(mine, gather_list=None, dst=0)
         elif self.rank == 0:
             dist.gather(radiance_sum, gather_list=[self.parts[r] for r in range(self.world_size)], dst=0)
         else:
