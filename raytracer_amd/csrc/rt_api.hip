@@ -184,6 +184,11 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
     const size_t image_bytes = (size_t)k.lds_words * 4;
     out->block_threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
+    // Worlds with spheres: one wave per workgroup.  Their waves last long and unevenly (every ray tests every
+    // sphere), and a workgroup keeps its waves' slots until its last wave ends (measured with 256 threads on the
+    // 4096-sphere scene: 2.8 of 4 possible waves resident on average; one wave per workgroup: +8 %).
+    if (ctx->sphere_count && image_bytes <= 8u * 1024u) out->block_threads = 64u;
+    if (const uint32_t forced = env_or("RT_BLOCK_THREADS", 0, 0, 1024)) out->block_threads = forced & ~63u ? forced & ~63u : 64u;   // experiments
     uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
     // The kernels index lanes and streams (pixel * lanes_per_pixel + batch) with 32-bit integers.
@@ -226,31 +231,31 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     return RT_OK;
 }
 
-template <int IMODE, int RMODE, bool MIXED, int STAGE>
+template <int IMODE, int RMODE, int PRIMS, int STAGE>
 hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels, float* d_radiance,
                           unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
-    auto kernel = rt::render_kernel<IMODE, RMODE, MIXED, STAGE>;
+    auto kernel = rt::render_kernel<IMODE, RMODE, PRIMS, STAGE>;
     const uint32_t blocks = STAGE == 2 ? L.stage2_blocks : L.blocks;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
                        d_rays, ws);
     return hipGetLastError();
 }
 
-// Every instantiation of the render kernel: (intersect mode, stream layout, mixed scene, stage).  Stages 1
-// and 2 exist for the per-pixel stream layout only.
-#define RT_FOR_EACH_KERNEL(X)                                                                   \
-    X(RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, true, 0) X(RT_INTERSECT_WIDE8, RT_RNG_ROW_SERIAL, false, 0) \
-    X(RT_INTERSECT_SCALAR, RT_RNG_ROW_SERIAL, false, 0)                                         \
-    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 0) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 0) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 0) \
-    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 1) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 1) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 1) \
-    X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, true, 2) X(RT_INTERSECT_WIDE8, RT_RNG_PIXEL, false, 2) X(RT_INTERSECT_SCALAR, RT_RNG_PIXEL, false, 2)
+// Every instantiation of the render kernel: (intersect mode, stream layout, primitive kinds, stage).  WIDE8,
+// the throughput mode, has a variant per primitive mix (rectangles only / spheres only / both); SCALAR runs the
+// general one.  Stages 1 and 2 exist for the per-pixel stream layout only.
+#define RT_FOR_EACH_STAGE(X, IM, PR)                                                             \
+    X(IM, RT_RNG_ROW_SERIAL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 1) X(IM, RT_RNG_PIXEL, PR, 2)
+#define RT_FOR_EACH_KERNEL(X)                                                                    \
+    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_RECTS) RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_SPHERES) \
+    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_BOTH) RT_FOR_EACH_STAGE(X, RT_INTERSECT_SCALAR, rt::PRIMS_BOTH)
 
 // Lets every render kernel variant use up to `bytes` of dynamic LDS on the current device.  Done once
 // per context at creation (with the device's maximum), so that a launch is nothing but a launch and can be
 // recorded into a HIP graph.
 hipError_t allow_dynamic_lds(size_t bytes) {
-#define RT_ALLOW(IM, RM, MX, ST)                                                                                             \
-    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rt::render_kernel<IM, RM, MX, ST>),                 \
+#define RT_ALLOW(IM, RM, PR, ST)                                                                                             \
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rt::render_kernel<IM, RM, PR, ST>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); e != hipSuccess)         \
         return e;
     RT_FOR_EACH_KERNEL(RT_ALLOW)
@@ -261,11 +266,13 @@ hipError_t allow_dynamic_lds(size_t bytes) {
 hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d_pixels, float* d_radiance,
                   unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
     const uint4* image = ctx->d_image[L.imode];
-    const size_t lds = (size_t)ctx->lds_words * 4;
-    const bool mixed = L.imode == RT_INTERSECT_WIDE8 && ctx->mixed;
-#define RT_DISPATCH(IM, RM, MX, ST)                                                  \
-    if (L.imode == IM && L.rmode == RM && mixed == MX && stage == ST)                \
-        return launch_variant<IM, RM, MX, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);
+    // the staged scene image, plus one 1 KiB sphere staging slice per wave when the world has spheres
+    const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * 1024u : 0u);
+    const int prims = L.imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
+                      : ctx->sphere_count ? rt::PRIMS_SPHERES : rt::PRIMS_RECTS;
+#define RT_DISPATCH(IM, RM, PR, ST)                                                  \
+    if (L.imode == IM && L.rmode == RM && prims == PR && stage == ST)                \
+        return launch_variant<IM, RM, PR, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);
     RT_FOR_EACH_KERNEL(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
@@ -644,10 +651,12 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
     std::vector<uint32_t> images[2] = {rt::pack_scene_image(*w, true), rt::pack_scene_image(*w, false)};
+    // a world with spheres also needs the waves' sphere staging slices: 1 KiB per wave, at most 16 waves per workgroup
+    const size_t staging = w->sphere_count ? 16u * 1024u : 0u;
     for (int i = 0; i < 2; ++i)
-        if ((size_t)images[i][rt::H_LDS_WORDS] * 4 > lds_limit)
+        if ((size_t)images[i][rt::H_LDS_WORDS] * 4 + staging > lds_limit)
             return fail(ctx, RT_ERR_TOO_LARGE, "planes, rectangles and materials take %zu bytes, the LDS of one workgroup holds %zu",
-                        (size_t)images[i][rt::H_LDS_WORDS] * 4, lds_limit);
+                        (size_t)images[i][rt::H_LDS_WORDS] * 4 + staging, lds_limit);
     // Both new images are allocated and filled before the context is touched, so a failure leaves the
     // previous world in place and usable.
     uint4* fresh[2] = {nullptr, nullptr};

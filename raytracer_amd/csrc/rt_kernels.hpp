@@ -53,6 +53,11 @@ struct Workspace {
 };
 constexpr uint32_t POOL_VEC4 = 5;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
 
+// Which primitive loops a kernel variant contains (planes are always there): a world without spheres runs a
+// variant without the sphere code and its registers, and the other way round.  PRIMS_BOTH in WIDE8 mode
+// also orders sphere/rectangle ties by the reference's AVX lane (see intersect_world).
+enum : int { PRIMS_RECTS = 1, PRIMS_SPHERES = 2, PRIMS_BOTH = 3 };
+
 struct V3 { float x, y, z; };
 
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -205,6 +210,7 @@ struct SceneView {
     const float* f;       // LDS image as floats
     const uint32_t* u;    // ... and as words
     const float4* gspheres;   // sphere records (cx cy cz r*r) in the global image
+    float4* wave_spheres;     // this wave's 64-record staging slice in LDS
     const uint32_t* gtags;    // sphere tags (material | lane << 24) in the global image
     uint32_t n_planes, n_spheres, n_rects;
     uint32_t off_planes, off_rects, off_mats;
@@ -272,15 +278,18 @@ __device__ __forceinline__ void update_closest_sphere(float t, float min_hit, ui
 
 // `camera_origin` (wave-uniform): every lane's ray starts at the camera position, so the rectangles'
 // origin transforms are read from the scene image, where the host stored them, instead of computed.
-template <int IMODE, bool MIXED>
+// Variants with spheres must be called by ALL 64 lanes of the wave (the lanes stage the sphere records
+// together); `active` says whether this lane has a ray, and only active lanes test anything.
+template <int IMODE, int PRIMS>
 __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
-                                                   bool camera_origin) {
+                                                   bool camera_origin, bool active) {
+    constexpr bool MIXED = PRIMS == PRIMS_BOTH && IMODE == RT_INTERSECT_WIDE8;
     float best_t = 3.402823466e+38f;  // F32Max
     uint32_t best_id = 0;
     uint32_t best_lane = 0;     // WIDE8 + MIXED: AVX lane of the best hit when it is a sphere
 
     // Planes: scalar code in both reference routines (main.cpp:37-50, 168-180).
-    for (uint32_t i = 0; i < sv.n_planes; ++i) {
+    for (uint32_t i = 0; i < (active ? sv.n_planes : 0u); ++i) {
         const float4 pl = *reinterpret_cast<const float4*>(sv.f + sv.off_planes + PLANE_WORDS * i);
         V3 n = mk(pl.x, pl.y, pl.z);
         float denom = dot(n, d);
@@ -290,13 +299,21 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         }
     }
 
-    // Spheres (main.cpp:60-91 / 182-207).  The part every sphere pays (b, c, discriminant) is evaluated
-    // for four spheres at a time, so that four independent chains and four LDS reads are in flight; the
-    // roots are only computed, sphere by sphere in slot order, when some lane of the wave needs them.
-    if (sv.n_spheres) {
+    // Spheres (main.cpp:60-91 / 182-207).  Every lane of the wave tests the same sphere, so the records
+    // (centre, r*r) are wanted in vector registers as wave-uniform values: arithmetic on vector registers
+    // only issues at twice the rate of instructions that read a scalar register on this chip.  The wave
+    // therefore stages 64 records at a time in its own 1 KiB slice of LDS - lane j loads record j of the
+    // chunk from global memory (one coalesced 1 KiB load, requested one chunk ahead) and stores it - and
+    // reads them back one by one with a wave-uniform address (a broadcast ds_read_b128).  LDS operations
+    // of one wave execute in order, so the slice needs no barrier and no second buffer.  The part every
+    // sphere pays (b, c, discriminant) is evaluated for four spheres at a time; the roots are only
+    // computed, sphere by sphere in slot order, when some lane of the wave needs them.
+    if ((PRIMS & PRIMS_SPHERES) && sv.n_spheres) {
         const float a = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(d, d) : dot(d, d);
         const float denom = 2.0f * a;
-        const float four_a = 4.0f * a;
+        const float minus_four_a = -4.0f * a;   // -(4a * c) is (-4a) * c: negation commutes with the rounding
+        // b = 2 * dot(d, cto) is computed as dot(2d, cto): scaling by two commutes with every rounding.
+        const V3 d2 = mk(2.0f * d.x, 2.0f * d.y, 2.0f * d.z);
         // Both roots are divided by the same 2a: the reciprocal estimate and its Newton step (the
         // first three operations of the IEEE division refinement, see div2) are done once per ray.
         float recip = __builtin_amdgcn_rcpf(denom);
@@ -308,13 +325,13 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         auto terms = [&](const float4 sp, float& b, float& c, float& disc) {
             V3 cto = o - mk(sp.x, sp.y, sp.z);
             if (IMODE == RT_INTERSECT_WIDE8) {
-                b = 2.0f * dot_fma(d, cto);
+                b = dot_fma(d2, cto);
                 c = dot_fma(cto, cto) - sp.w;
-                disc = __builtin_fmaf(b, b, -(four_a * c));        // FMulSub(b, b, 4ac)
+                disc = __builtin_fmaf(b, b, minus_four_a * c);     // FMulSub(b, b, 4ac)
             } else {
-                b = 2 * dot(d, cto);
+                b = d2.x * cto.x + d2.y * cto.y + d2.z * cto.z;    // 2 * (d . cto), rounded as the products and sums of d . cto
                 c = dot(cto, cto) - sp.w;
-                disc = b * b - four_a * c;
+                disc = b * b + minus_four_a * c;                   // b*b - 4ac: adding the negated product is the subtraction
             }
         };
         // disc > 0: the ray's line meets the sphere.  With b > 0 and c > 0 (centre behind the
@@ -338,29 +355,58 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
             update_closest_sphere<MIXED>(t, min_hit, sphere_base + k, MIXED ? sv.gtags[k] >> TAG_LANE_SHIFT : 0u,
                                          best_t, best_id, best_lane);
         };
+        // Is any of four discriminants possibly positive?  As integers, the AND of the four has its sign
+        // bit set exactly when all four are negative or -0; +0 passes, and `roots` tests each one exactly.
+        auto any_candidate = [](float d0, float d1, float d2_, float d3) {
+            return (int32_t)(__float_as_uint(d0) & __float_as_uint(d1) & __float_as_uint(d2_) & __float_as_uint(d3)) >= 0;
+        };
 
-        // Groups of four: the records of the next group are requested before the current one is worked on.
-        const uint32_t groups = sv.n_spheres / 4;
-        const float4* rec = sv.gspheres;
-        float4 s0, s1, s2, s3;
-        if (groups) { s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
-        for (uint32_t g = 0; g < groups; ++g) {
-            const float4* next = rec + 4 * (g + 1 < groups ? g + 1 : g);
-            const float4 n0 = next[0], n1 = next[1], n2 = next[2], n3 = next[3];
-            float b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
-            terms(s0, b0, c0, d0); terms(s1, b1, c1, d1); terms(s2, b2, c2, d2); terms(s3, b3, c3, d3);
-            if (d0 > 0.0f || d1 > 0.0f || d2 > 0.0f || d3 > 0.0f) {
-                roots(4 * g, b0, c0, d0);
-                roots(4 * g + 1, b1, c1, d1);
-                roots(4 * g + 2, b2, c2, d2);
-                roots(4 * g + 3, b3, c3, d3);
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t chunks = (sv.n_spheres + 63u) / 64u;
+        const uint32_t last = sv.n_spheres - 1u;
+        float4 staged = sv.gspheres[min(lane, last)];
+        for (uint32_t chunk = 0; chunk < chunks; ++chunk) {
+            sv.wave_spheres[lane] = staged;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (chunk + 1 < chunks) staged = sv.gspheres[min(64u * (chunk + 1) + lane, last)];   // next chunk: in flight while this one is tested
+            const uint32_t first = 64u * chunk;
+            const uint32_t count = min(64u, sv.n_spheres - first);
+            const uint32_t groups = count / 4u;
+            const float4* rec = sv.wave_spheres;
+            if (active) {
+            // Groups of four.  The records of the next group are read from LDS before the current group is
+            // worked on, so their latency is covered by arithmetic even with few waves on the SIMD; two
+            // register sets take turns (A, B), so nothing is copied from "next" to "current".
+            auto group = [&](uint32_t g, const float4 s0, const float4 s1, const float4 s2, const float4 s3) {
+                float b0, b1, b2, b3, c0, c1, c2, c3, e0, e1, e2, e3;
+                terms(s0, b0, c0, e0); terms(s1, b1, c1, e1); terms(s2, b2, c2, e2); terms(s3, b3, c3, e3);
+                if (any_candidate(e0, e1, e2, e3)) {
+                    roots(first + 4 * g, b0, c0, e0);
+                    roots(first + 4 * g + 1, b1, c1, e1);
+                    roots(first + 4 * g + 2, b2, c2, e2);
+                    roots(first + 4 * g + 3, b3, c3, e3);
+                }
+            };
+            float4 a0, a1, a2, a3;
+            if (groups) { a0 = rec[0]; a1 = rec[1]; a2 = rec[2]; a3 = rec[3]; }
+            uint32_t g = 0;
+            for (; g + 2u <= groups; g += 2u) {
+                const float4* nb = rec + 4u * (g + 1u);
+                const float4 b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3];
+                group(g, a0, a1, a2, a3);
+                const float4* na = rec + 4u * min(g + 2u, groups - 1u);
+                a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3];
+                group(g + 1u, b0, b1, b2, b3);
             }
-            s0 = n0; s1 = n1; s2 = n2; s3 = n3;
-        }
-        for (uint32_t k = 4 * groups; k < sv.n_spheres; ++k) {
-            float b, c, disc;
-            terms(rec[k], b, c, disc);
-            roots(k, b, c, disc);
+            if (g < groups) group(g, a0, a1, a2, a3);
+            for (uint32_t k = 4 * groups; k < count; ++k) {
+                float b, c, disc;
+                terms(rec[k], b, c, disc);
+                roots(first + k, b, c, disc);
+            }
+            }
+            __builtin_amdgcn_wave_barrier();   // the next chunk's store stays behind these reads
         }
     }
 
@@ -371,7 +417,7 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     const F2 ox2 = splat(o.x), oy2 = splat(o.y), oz2 = splat(o.z);
     const F2 dx2 = splat(d.x), dy2 = splat(d.y), dz2 = splat(d.z);
     const uint32_t rect_base = 1 + sv.n_planes + sv.n_spheres;
-    for (uint32_t pair = 0; pair < sv.n_rects / 2; ++pair) {
+    for (uint32_t pair = 0; pair < ((PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u); ++pair) {
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
         const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3], z01 = rec[4], z23 = rec[5];
         F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
@@ -412,7 +458,7 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                 continue;
             }
             bool closer = t < best_t;
-            if (MIXED && IMODE == RT_INTERSECT_WIDE8) {
+            if (MIXED) {
                 // A sphere and a rectangle at exactly the same t: the reference keeps the lower
                 // AVX lane, and within one lane the sphere, which it tested first.
                 uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
@@ -435,7 +481,7 @@ struct Hit { V3 normal; uint32_t material; };
 
 // Normal and material of the winning primitive, as the reference computes them
 // at the moment it accepts the hit.
-template <int IMODE>
+template <int IMODE, int PRIMS>
 __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id, float t, V3 o, V3 d) {
     Hit h;
     uint32_t id = best_id - 1;
@@ -443,7 +489,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
         const float* pl = sv.f + sv.off_planes + PLANE_WORDS * id;
         h.normal = load3(pl);
         h.material = sv.u[sv.off_planes + PLANE_WORDS * id + 4];
-    } else if (id < sv.n_planes + sv.n_spheres) {
+    } else if ((PRIMS & PRIMS_SPHERES) && (!(PRIMS & PRIMS_RECTS) || id < sv.n_planes + sv.n_spheres)) {
         uint32_t k = id - sv.n_planes;
         const float4 sp = sv.gspheres[k];
         V3 c = mk(sp.x, sp.y, sp.z);
@@ -529,7 +575,7 @@ constexpr int BLOCK_THREADS = 256;   // resolve_kernel
 // the end with the same loop.  pixel_combine_kernel then adds the lanes_per_pixel sums of every pixel with a deposited stream in
 // the order of the STAGE 0 tree and writes the pixel.  A stream is computed by the same operations in the
 // same order wherever it runs, so the results are those of STAGE 0 bit for bit.
-template <int IMODE, int RMODE, bool MIXED, int STAGE>
+template <int IMODE, int RMODE, int PRIMS, int STAGE>
 __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams p, const uint4* __restrict__ scene_image,
                                                                uint32_t* __restrict__ pixels,
                                                                float* __restrict__ radiance,
@@ -544,6 +590,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     sv.u = reinterpret_cast<const uint32_t*>(lds_image);
     sv.n_planes = sv.u[H_NPLANES]; sv.n_spheres = p.sphere_count; sv.n_rects = sv.u[H_NRECTS];
     sv.gspheres = reinterpret_cast<const float4*>(scene_image) + p.sphere_offset / 4;
+    sv.wave_spheres = reinterpret_cast<float4*>(lds_image + p.lds_words / 4) + 64u * (threadIdx.x >> 6);
     sv.gtags = reinterpret_cast<const uint32_t*>(scene_image) + p.sphere_tag_offset;
     sv.off_planes = sv.u[H_OFF_PLANES];
     sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
@@ -688,14 +735,23 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             break;   // hand the tail over: few lanes left, each with little left to do
 
         // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
+        // Worlds with spheres: every lane of the wave enters the intersection (the lanes stage the sphere
+        // records together), lanes without a ray only help with that.
+        const bool camera_origin = __ballot(in_path && bounce != 0) == 0ull;   // all rays of the wave are primary rays
+        Closest c;
+        if (PRIMS & PRIMS_SPHERES) {
+            if (in_path) rd = normalize(next_dir);
+            c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, in_path);
+        }
         if (in_path) {
-            rd = normalize(next_dir);
-            const bool camera_origin = __ballot(bounce != 0) == 0ull;   // all rays of the wave are primary rays
-            const Closest c = intersect_world<IMODE, MIXED>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin);
+            if (!(PRIMS & PRIMS_SPHERES)) {
+                rd = normalize(next_dir);
+                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, true);
+            }
             ++pixel_rays;
             ++bounce;
             if (c.id != 0) {
-                Hit h = resolve_hit<IMODE>(sv, c.id, c.t, ro, rd);
+                Hit h = resolve_hit<IMODE, PRIMS>(sv, c.id, c.t, ro, rd);
                 const float4* m = reinterpret_cast<const float4*>(sv.f + sv.off_mats + MAT_WORDS * h.material);
                 const float4 m0 = m[0], m1 = m[1], m2 = m[2];   // color ri | emit reflection | 1/ri r0
                 result = result + attenuation * mk(m1.x, m1.y, m1.z);
