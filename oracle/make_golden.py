@@ -8,6 +8,7 @@ counts of full-size renders.
 
   python oracle/make_golden.py            # small fixtures (seconds)
   python oracle/make_golden.py --full     # also the 1280x720x512 known answers (minutes)
+  python oracle/make_golden.py --reference-images   # only the 320x180x64 reference radiance images (seconds)
 """
 import argparse
 import hashlib
@@ -43,13 +44,30 @@ def render(binary, scene, w, h, spp, tmp, rows_per_order=1, threads=8):
     return info, rad, pix, hashlib.md5(pathlib.Path(f"{prefix}.bmp").read_bytes()).hexdigest()
 
 
+def reference_images():
+    """The reference's own 320x180 renders at 64 spp (strict build, one row per work order, its row seeds)
+    of the Cornell box, its spheres scene and the glass3 scene, as linear radiance + packed pixels + ray
+    count: what the tolerance tests (per-pixel max-abs on linear radiance, PSNR of the 8-bit image) compare
+    against."""
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, scene in (("cornell", "cornell"), ("spheres", "spheres"), ("glass3", GOLDEN / "glass3.rtsc")):
+            info, rad, pix, md5 = render(STRICT, scene, 320, 180, 64, tmp)
+            np.savez_compressed(GOLDEN / f"reference_{name}_320x180_64spp.npz", radiance=rad, pixels=pix,
+                                rays=np.uint64(info["rays"]))
+            print("reference image", name, info["rays"], md5, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--reference-images", action="store_true")
     args = ap.parse_args()
     if not STRICT.exists() or not SHIPPED.exists():
         raise SystemExit("build the reference harness first: make -C oracle ref")
     GOLDEN.mkdir(parents=True, exist_ok=True)
+    if args.reference_images:
+        reference_images()
+        return
     from raytracer_amd.host_scene import build_scene
     from raytracer_amd.scene_io import write_scene
 
@@ -92,6 +110,7 @@ def main():
                         "mean_radiance": [float(x) for x in rad.reshape(-1, 3).mean(axis=0, dtype=np.float64)],
                     }
                     print(scene, w, h, spp, build, info["rays"], md5, flush=True)
+    reference_images()
     path = GOLDEN / "known_answers.json"
     old = json.loads(path.read_text()) if path.exists() else {}
     old.update(known)

@@ -248,6 +248,10 @@ uint32_t rto_pack_srgb(const float rgb[3]) {
             (uint32_t)((int32_t)(255 * rto_linear_to_srgb(rgb[2])) << 0));
 }
 
+void rto_pack_srgb_many(const float* rgb, uint64_t count, uint32_t* out) {
+    for (uint64_t i = 0; i < count; ++i) out[i] = rto_pack_srgb(rgb + 3 * i);
+}
+
 /* ---------------------------------------------------------------- main.cpp:163-242 */
 static int intersect_scalar(const rto_scene* s, float min_hit, float plane_tol, v3 o, v3 d,
                             float* t_out, uint32_t* mat_out, v3* n_out) {

@@ -83,6 +83,7 @@ int   rto_refract(const float incident[3], const float normal[3], float refracti
 float rto_schlick(const float incident[3], const float normal[3], float refractive_index);
 float rto_linear_to_srgb(float v);
 uint32_t rto_pack_srgb(const float rgb[3]);
+void rto_pack_srgb_many(const float* rgb, uint64_t count, uint32_t* out);   /* count pixels of 3 floats */
 uint32_t rto_pixel_stream_seed(uint32_t seed_constant, uint32_t x, uint32_t y, uint32_t batch);
 
 /* One world intersection.  Returns 1 on hit; t, material, normal as the reference leaves them. */

@@ -67,6 +67,8 @@ def lib():
         L.rto_linear_to_srgb.argtypes = [C.c_float]
         L.rto_pack_srgb.restype = C.c_uint32
         L.rto_pack_srgb.argtypes = [C.c_void_p]
+        L.rto_pack_srgb_many.restype = None
+        L.rto_pack_srgb_many.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.rto_pixel_stream_seed.restype = C.c_uint32
         L.rto_pixel_stream_seed.argtypes = [C.c_uint32] * 4
         L.rto_intersect.restype = C.c_int
@@ -94,6 +96,14 @@ def default_params(width, height, spp, **overrides) -> Params:
 
 def _ptr(arr):
     return arr.ctypes.data_as(C.c_void_p) if arr is not None and arr.size else None
+
+
+def pack_srgb(radiance: np.ndarray) -> np.ndarray:
+    """The reference's tonemap + pack (math_util.h:102-125, glibc powf) of a [..., 3] float32 image."""
+    radiance = np.ascontiguousarray(radiance, dtype=np.float32)
+    out = np.zeros(radiance.shape[:-1], dtype=np.uint32)
+    lib().rto_pack_srgb_many(_ptr(radiance), out.size, _ptr(out))
+    return out
 
 
 class OracleScene:

@@ -114,6 +114,14 @@ def test_cornell_full_size_known_answer(ctx, cornell, golden_dir):
     pix, rad, rays = ctx.render(B.default_params(1280, 720, 512, rng_mode=B.RNG_ROW_SERIAL))
     assert rays == k["rays"] == 1293078337
     assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
+    # 8-bit image: the reference's own tonemap (glibc powf) of that radiance is the reference's pixel image ...
+    ref_pix = O.pack_srgb(rad)
+    assert hashlib.sha256(ref_pix.tobytes()).hexdigest() == k["pixels_sha256"]
+    # ... and the device's (pow evaluated in double, rounded once) differs from it by one LSB in a few channels
+    diff = np.abs(channels(pix) - channels(ref_pix))
+    print(f"\n1280x720x512 Cornell: {int((diff != 0).sum())} of {diff.size} 8-bit channels differ from the reference's, "
+          f"max {int(diff.max())} LSB, PSNR {psnr8(pix, ref_pix):.2f} dB")
+    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
 
 
 def test_spheres_full_size_scalar_routine(ctx, spheres, golden_dir):
