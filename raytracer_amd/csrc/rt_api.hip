@@ -266,8 +266,8 @@ hipError_t allow_dynamic_lds(size_t bytes) {
 hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d_pixels, float* d_radiance,
                   unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
     const uint4* image = ctx->d_image[L.imode];
-    // the staged scene image, plus one 1 KiB sphere staging slice per wave when the world has spheres
-    const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * 1024u : 0u);
+    // the staged scene image, plus one sphere staging slice per wave when the world has spheres
+    const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * rt::SPHERE_SLICE_BYTES : 0u);
     const int prims = L.imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
                       : ctx->sphere_count ? rt::PRIMS_SPHERES : rt::PRIMS_RECTS;
 #define RT_DISPATCH(IM, RM, PR, ST)                                                  \
@@ -509,7 +509,12 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
     constexpr size_t warm_bytes = 1u << 20;
     void* d_warm = nullptr;
     const size_t lds_max = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
-    if (allow_dynamic_lds(lds_max) != hipSuccess ||
+#ifdef RT_STAMPS
+    const size_t lds_static = 4096;   // the diagnostic build's per-wave tables
+#else
+    const size_t lds_static = 0;
+#endif
+    if (allow_dynamic_lds(lds_max - lds_static) != hipSuccess ||
         ensure_staging(ctx, warm_bytes) != RT_OK || hipMalloc(&d_warm, warm_bytes) != hipSuccess ||
         hipMemsetAsync(d_warm, 0, warm_bytes, nullptr) != hipSuccess ||
         hipMemcpyAsync(ctx->h_staging, d_warm, warm_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
@@ -651,8 +656,8 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
     std::vector<uint32_t> images[2] = {rt::pack_scene_image(*w, true), rt::pack_scene_image(*w, false)};
-    // a world with spheres also needs the waves' sphere staging slices: 1 KiB per wave, at most 16 waves per workgroup
-    const size_t staging = w->sphere_count ? 16u * 1024u : 0u;
+    // a world with spheres also needs the waves' sphere staging slices, at most 16 waves per workgroup
+    const size_t staging = w->sphere_count ? 16u * rt::SPHERE_SLICE_BYTES : 0u;
     for (int i = 0; i < 2; ++i)
         if ((size_t)images[i][rt::H_LDS_WORDS] * 4 + staging > lds_limit)
             return fail(ctx, RT_ERR_TOO_LARGE, "planes, rectangles and materials take %zu bytes, the LDS of one workgroup holds %zu",
@@ -864,6 +869,18 @@ rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_
                      uint32_t* pixels, float* radiance_mean) {
     return guarded([&] { return resolve_impl(ctx, radiance_sum, pixel_count, total_samples, pixels, radiance_mean); });
 }
+
+#ifdef RT_STAMPS
+// Diagnostic build only: reads (and optionally clears) the table of per-region cycle sums and event counts.
+int rt_debug_read_stamps(unsigned long long* out, int clear) {
+    void* address = nullptr;
+    if (hipGetSymbolAddress(&address, HIP_SYMBOL(rt::rt_stamp_table)) != hipSuccess) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out && hipMemcpy(out, address, sizeof(unsigned long long) * rt::ST_COUNT, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (clear && hipMemset(address, 0, sizeof(unsigned long long) * rt::ST_COUNT) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 
 rt_status rt_last_kernel_ms(rt_context* ctx, float* out_ms) {
     if (!ctx || !out_ms) return RT_ERR_INVALID_ARGUMENT;

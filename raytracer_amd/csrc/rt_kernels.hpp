@@ -51,7 +51,54 @@ struct Workspace {
     uint4* pool;              // POOL_VEC4 x uint4 per deposited stream
     uint32_t* pool_count;     // streams deposited by STAGE 1
 };
-constexpr uint32_t POOL_VEC4 = 5;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
+constexpr uint32_t POOL_VEC4 = 5;
+// Per-wave LDS slice of worlds with spheres: 64 staged sphere records.
+constexpr uint32_t SPHERE_SLICE_BYTES = 1024u;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
+
+// Diagnostic build only (-DRT_STAMPS, never the shipped library): every wave adds up the shader-clock
+// cycles it spends in each region of the render loop, and a few event counts, and adds them to a global
+// table when it ends.  The stamps cost about a tenth of the run time, so the table is read as shares.
+enum : int { ST_START = 0, ST_CONTROL, ST_PLANES, ST_SPHERE_TERMS, ST_SPHERE_ROOTS, ST_RECTS, ST_RESOLVE, ST_SHADE, ST_EPILOGUE,
+             CT_ITERATIONS, CT_LANES_TRACING, CT_ROOTS_BODIES, CT_ROOTS_LANES, CT_START_LANES, CT_HIT_LANES, CT_DIELECTRIC_BODIES,
+             CT_DIELECTRIC_LANES, ST_COUNT };
+constexpr int MAX_STAMP_WAVES = 16;
+#ifdef RT_STAMPS
+__device__ unsigned long long rt_stamp_table[ST_COUNT];
+// The wave's sums live in LDS and are updated by the first ACTIVE lane, so that marks inside divergent code
+// are recorded whichever lanes happen to run it.
+struct Stamps {
+    unsigned long long* slot;   // [ST_COUNT + 1] of this wave; the last word is the time of the previous mark
+    __device__ __forceinline__ bool first_active() const {
+        return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true));
+    }
+    __device__ __forceinline__ void begin() {
+        __shared__ unsigned long long table[MAX_STAMP_WAVES][ST_COUNT + 1];
+        slot = table[threadIdx.x >> 6];
+        if ((threadIdx.x & 63u) == 0) {
+            for (int i = 0; i < ST_COUNT; ++i) slot[i] = 0;
+            slot[ST_COUNT] = __builtin_amdgcn_s_memtime();
+        }
+    }
+    __device__ __forceinline__ void mark(int region) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (first_active()) { slot[region] += now - slot[ST_COUNT]; slot[ST_COUNT] = now; }
+    }
+    __device__ __forceinline__ void count(int counter, unsigned long long n) { if (first_active()) slot[counter] += n; }
+    __device__ __forceinline__ void flush() {
+        if ((threadIdx.x & 63u) == 0)
+            for (int i = 0; i < ST_COUNT; ++i) atomicAdd(&rt_stamp_table[i], slot[i]);
+    }
+};
+#define RT_LANES(pred) ((unsigned long long)__builtin_popcountll(__ballot(pred)))
+#else
+struct Stamps {
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void count(int, unsigned long long) {}
+    __device__ __forceinline__ void flush() {}
+};
+#define RT_LANES(pred) 0ull
+#endif
 
 // Which primitive loops a kernel variant contains (planes are always there): a world without spheres runs a
 // variant without the sphere code and its registers, and the other way round.  PRIMS_BOTH in WIDE8 mode
@@ -213,7 +260,7 @@ struct SceneView {
     const float* f;       // LDS image as floats
     const uint32_t* u;    // ... and as words
     const float4* gspheres;   // sphere records (cx cy cz r*r) in the global image
-    float4* wave_spheres;     // this wave's 64-record staging slice in LDS
+    float4* wave_spheres;     // this wave's LDS slice: 64 staged sphere records
     const uint32_t* gtags;    // sphere tags (material | lane << 24) in the global image
     uint32_t n_planes, n_spheres, n_rects;
     uint32_t off_planes, off_rects, off_mats;
@@ -285,7 +332,7 @@ __device__ __forceinline__ void update_closest_sphere(float t, float min_hit, ui
 // together); `active` says whether this lane has a ray, and only active lanes test anything.
 template <int IMODE, int PRIMS>
 __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
-                                                   bool camera_origin, bool active) {
+                                                   bool camera_origin, bool active, Stamps& st) {
     constexpr bool MIXED = PRIMS == PRIMS_BOTH && IMODE == RT_INTERSECT_WIDE8;
     float best_t = 3.402823466e+38f;  // F32Max
     uint32_t best_id = 0;
@@ -302,6 +349,7 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         }
     }
 
+    st.mark(ST_PLANES);
     // Spheres (main.cpp:60-91 / 182-207).  Every lane of the wave tests the same sphere, so the records
     // (centre, r*r) are wanted in vector registers as wave-uniform values: arithmetic on vector registers
     // only issues at twice the rate of instructions that read a scalar register on this chip.  The wave
@@ -342,6 +390,8 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         // the reference computes them and rejects them against min_hit >= 0; skip them unevaluated.
         auto roots = [&](uint32_t k, float b, float c, float disc) {
             if (!(disc > 0.0f) || (b > 0.0f && c > 0.0f)) return;
+            st.count(CT_ROOTS_BODIES, 1);
+            st.count(CT_ROOTS_LANES, RT_LANES(true));
             const float root = sqrt_exact(disc);
             // (tp, tn) = ((-b + root) / 2a, (-b - root) / 2a), correctly rounded (see div2)
             const F2 num = f2(-b + root, -b - root);
@@ -385,10 +435,12 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                 float b0, b1, b2, b3, c0, c1, c2, c3, e0, e1, e2, e3;
                 terms(s0, b0, c0, e0); terms(s1, b1, c1, e1); terms(s2, b2, c2, e2); terms(s3, b3, c3, e3);
                 if (any_candidate(e0, e1, e2, e3)) {
+                    st.mark(ST_SPHERE_TERMS);
                     roots(first + 4 * g, b0, c0, e0);
                     roots(first + 4 * g + 1, b1, c1, e1);
                     roots(first + 4 * g + 2, b2, c2, e2);
                     roots(first + 4 * g + 3, b3, c3, e3);
+                    st.mark(ST_SPHERE_ROOTS);
                 }
             };
             float4 a0, a1, a2, a3;
@@ -413,6 +465,7 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         }
     }
 
+    st.mark(ST_SPHERE_TERMS);
     // Rectangles (main.cpp:96-129 / 212-239): ray into the rectangle's frame, hit the
     // z = 0 plane, test against the unit square.  Two rectangles (A, B) per step (the scene image stores
     // them interleaved: rows 0 and 1 of A, of B, then the two row-2 vectors), which gives the scheduler
@@ -474,6 +527,7 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
             }
         }
     }
+    st.mark(ST_RECTS);
     Closest c;
     c.t = best_t;
     c.id = best_id;
@@ -593,7 +647,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     sv.u = reinterpret_cast<const uint32_t*>(lds_image);
     sv.n_planes = sv.u[H_NPLANES]; sv.n_spheres = p.sphere_count; sv.n_rects = sv.u[H_NRECTS];
     sv.gspheres = reinterpret_cast<const float4*>(scene_image) + p.sphere_offset / 4;
-    sv.wave_spheres = reinterpret_cast<float4*>(lds_image + p.lds_words / 4) + 64u * (threadIdx.x >> 6);
+    sv.wave_spheres = reinterpret_cast<float4*>(lds_image + p.lds_words / 4) + (SPHERE_SLICE_BYTES / 16u) * (threadIdx.x >> 6);
     sv.gtags = reinterpret_cast<const uint32_t*>(scene_image) + p.sphere_tag_offset;
     sv.off_planes = sv.u[H_OFF_PLANES];
     sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
@@ -661,6 +715,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     // STAGE 2: the pool is dealt to the waves in groups of 64 entries, group g to wave g mod (number of
     // waves); a wave walks through its entries with a cursor that all its lanes advance together.
     uint32_t wave_cursor = 0;
+    Stamps st;
+    st.begin();
     while (true) {
         uint32_t fetch_slot = 0xFFFFFFFFu;
         if (STAGE == 2) {
@@ -673,6 +729,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         // ---- lanes between paths: close the pixel if it is complete, start the next sample
         //      (main.cpp:379-388).  Only the un-normalised primary direction is formed here; the
         //      normalisation below is shared with the lanes that continue a path.
+        st.count(CT_START_LANES, RT_LANES(need_sample));
         if (need_sample) {
             need_sample = false;
             if (samples_left == 0) {
@@ -731,6 +788,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 in_path = true;
             }
         }
+        st.mark(ST_START);
         const unsigned long long active = __ballot(in_path);
         if (active == 0ull) break;   // no lane of the wave has a ray left
         if (STAGE == 1 && (uint32_t)__builtin_popcountll(active) <= p.pool_threshold &&
@@ -742,19 +800,25 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         // records together), lanes without a ray only help with that.
         const bool camera_origin = __ballot(in_path && bounce != 0) == 0ull;   // all rays of the wave are primary rays
         Closest c;
+        st.count(CT_ITERATIONS, 1);
+        st.count(CT_LANES_TRACING, RT_LANES(in_path));
         if (PRIMS & PRIMS_SPHERES) {
             if (in_path) rd = normalize(next_dir);
-            c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, in_path);
+            st.mark(ST_CONTROL);
+            c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, in_path, st);
         }
         if (in_path) {
             if (!(PRIMS & PRIMS_SPHERES)) {
                 rd = normalize(next_dir);
-                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, true);
+                st.mark(ST_CONTROL);
+                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, true, st);
             }
             ++pixel_rays;
             ++bounce;
+            st.count(CT_HIT_LANES, RT_LANES(c.id != 0));
             if (c.id != 0) {
                 Hit h = resolve_hit<IMODE, PRIMS>(sv, c.id, c.t, ro, rd);
+                st.mark(ST_RESOLVE);
                 const float4* m = reinterpret_cast<const float4*>(sv.f + sv.off_mats + MAT_WORDS * h.material);
                 const float4 m0 = m[0], m1 = m[1], m2 = m[2];   // color ri | emit reflection | 1/ri r0
                 result = result + attenuation * mk(m1.x, m1.y, m1.z);
@@ -780,6 +844,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 const uint32_t pick = xorshift32(state);   // RandomUnilateral of main.cpp:318, drawn for every material
                 next_dir = reflected;
                 if (m0.w != 0.0f) {
+                    st.count(CT_DIELECTRIC_BODIES, 1);
+                    st.count(CT_DIELECTRIC_LANES, RT_LANES(true));
                     float fresnel = 1.0f;
                     V3 refracted = reflected;
                     if (refract(rd, n, m0.w, m2.x, refracted)) fresnel = schlick(rd, n, m2.y);
@@ -797,6 +863,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 need_sample = true;
             }
         }
+        st.mark(ST_SHADE);
     }
 
     // ---- epilogue ------------------------------------------------------------------
@@ -843,6 +910,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         if (pixel_valid && !pixel_pending && (threadIdx.x % p.lanes_per_pixel) == 0)
             emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
     }
+    st.mark(ST_EPILOGUE);
+    st.flush();
     // Ray counter: one 64-bit atomic per wave (main.cpp:397).
     for (int offset = 32; offset > 0; offset >>= 1) ray_count += __shfl_down(ray_count, offset);
     if ((threadIdx.x & 63) == 0 && ray_count != 0 && rays) atomicAdd(rays, ray_count);
