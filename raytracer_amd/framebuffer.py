@@ -107,10 +107,17 @@ def render_progressive(ctx, params, passes: int, accumulator: Accumulator | None
     from . import binding as B
     if params.rng_mode != B.RNG_PIXEL:
         raise ValueError("progressive rendering needs RNG_PIXEL: a row-serial stream has no second batch")
+    if (params.row_begin, params.row_end) != (0, params.height) or (params.band_rows and params.band_count > 1):
+        raise ValueError("progressive rendering keeps a full-image sum: params must cover every row of the image")
+    world = scene_hash(ctx._scene) if getattr(ctx, "_scene", None) is not None else 0
+    settings = settings_hash(params)
     acc = accumulator or Accumulator(params.width, params.height, lanes_per_pixel=params.lanes_per_pixel,
-                                     settings_hash=settings_hash(params))
+                                     scene_hash=world, settings_hash=settings)
     if (acc.width, acc.height, acc.lanes_per_pixel) != (params.width, params.height, params.lanes_per_pixel):
         raise ValueError("accumulator belongs to another image size or lanes_per_pixel")
+    # A sum of another scene or estimator must not be continued (the C++ driver refuses the same way, --resume).
+    if acc.samples > 0 and (acc.scene_hash != world or acc.settings_hash != settings):
+        raise ValueError("accumulator belongs to another scene or to other render settings (seed, bounces, spp, mode)")
     # The running sum stays in the context (FLAG_ACCUMULATE adds each pass to it on the GPU, in the order a host
     # loop `sum += pass` would); it is copied back for a checkpoint and after the last pass.
     flags, offset = params.flags, params.batch_offset

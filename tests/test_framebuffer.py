@@ -143,6 +143,17 @@ def test_progressive_passes_resume_bit_exactly(tmp_path, spheres):
             F.render_progressive(ctx, B.default_params(96, 54, 16, lanes_per_pixel=2), 1, accumulator=loaded)
         with pytest.raises(B.RtError):
             ctx.resolve(straight.sum, 0)
+        # the file records the scene and the settings; a sum is not continued under another seed, another
+        # scene, or with parameters that cover only part of the image
+        assert loaded.scene_hash == F.scene_hash(spheres) == H.world_hash("spheres") and loaded.scene_hash != 0
+        with pytest.raises(ValueError, match="another scene or to other render settings"):
+            F.render_progressive(ctx, B.default_params(96, 54, 16, lanes_per_pixel=4, seed_constant=777767), 1, accumulator=loaded)
+        with pytest.raises(ValueError, match="every row"):
+            F.render_progressive(ctx, B.default_params(96, 54, 16, lanes_per_pixel=4, row_begin=8, row_end=40), 1)
+        ctx.upload_world(H.build_scene("cornell"))
+        with pytest.raises(ValueError, match="another scene"):
+            F.render_progressive(ctx, p, 1, accumulator=loaded)
+        ctx.upload_world(spheres)
 
 
 @pytest.mark.gpu

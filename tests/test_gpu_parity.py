@@ -625,3 +625,47 @@ def test_sample_sharded_composition_equals_one_render_of_all_batches(ctx, cornel
     _, rad, whole_rays = check_against_oracle(ctx, cornell, whole)
     assert int(rays.sum()) == whole_rays
     assert np.array_equal(bits(total.cpu().numpy()), bits(rad))
+
+
+# ---------------------------------------------------------------- limits of the entry points
+
+def test_two_contexts_render_concurrently_on_two_streams(cornell, spheres):
+    """A compacted render's workspace belongs to its context, so concurrent renders need one context per
+    stream: two contexts, two streams, renders enqueued alternately without waiting - each gives the image
+    of a render on its own."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cases = [(cornell, B.default_params(320, 180, 256, lanes_per_pixel=4, flags=B.FLAG_COMPACT_TAILS)),
+             (spheres, B.default_params(256, 144, 256, lanes_per_pixel=2, flags=B.FLAG_COMPACT_TAILS))]
+    contexts, expected, streams, outputs = [], [], [], []
+    for scene, p in cases:
+        c = B.Context(0)
+        c.upload_world(scene)
+        c.reserve(p)
+        contexts.append(c)
+        expected.append(c.render(p, want_radiance=False))
+        streams.append(torch.cuda.Stream(dev))
+        outputs.append((torch.zeros((p.height, p.width), dtype=torch.int32, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)))
+    for repeat in range(3):
+        for (scene, p), c, s, (pix, rays) in zip(cases, contexts, streams, outputs):
+            c.render_device(p, pix.data_ptr(), None, rays.data_ptr() + 8 * repeat, s.cuda_stream)
+    torch.cuda.synchronize(dev)
+    for (want_pix, _, want_rays), (pix, rays) in zip(expected, outputs):
+        assert np.array_equal(pix.cpu().numpy().view(np.uint32), want_pix)
+        assert rays.cpu().tolist() == [want_rays] * 3
+    for c in contexts:
+        c.close()
+
+
+def test_size_and_sharing_limits_are_refused(ctx, cornell):
+    ctx.upload_world(cornell)
+    # lanes and streams are indexed with 32 bits: 65536 x 65536 pixels at 4 lanes per pixel is refused, not wrapped
+    with pytest.raises(B.RtError) as e:
+        ctx.reserve(B.default_params(65536, 65536, 4, lanes_per_pixel=4))
+    assert e.value.status == 1 and "2^32" in str(e.value)
+    # a context keeps one running sum: listed twice, it cannot render sums through rt_render_multi
+    with pytest.raises(B.RtError) as e:
+        B.render_multi([ctx, ctx], B.default_params(64, 36, 8, flags=B.FLAG_OUTPUT_SUM))
+    assert e.value.status == 1 and "more than once" in str(e.value)
+    pix, _, _ = B.render_multi([ctx, ctx], B.default_params(64, 36, 8))      # plain renders may share a context
+    assert np.array_equal(pix, ctx.render(B.default_params(64, 36, 8))[0])
