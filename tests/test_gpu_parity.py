@@ -238,9 +238,9 @@ def test_stress_scenes_reduced_size(ctx):
     check_against_oracle(ctx, build_scene("random_spheres", 4096, 1), B.default_params(64, 36, 4))
     check_against_oracle(ctx, build_scene("glass_spheres", 5), B.default_params(64, 36, 16, max_bounces=32))
     # spheres live in global memory, so their number is not bounded by the LDS: 20000 spheres (400 KB), and
-    # counts that leave 1..3 spheres after the groups of four
+    # counts that leave 1..3 spheres after the groups of four, and counts around the 64-record staging chunks
     check_against_oracle(ctx, build_scene("random_spheres", 20000, 1), B.default_params(32, 18, 2))
-    for count in (1, 2, 3, 5, 6, 7):
+    for count in (1, 2, 3, 5, 6, 7, 63, 64, 65, 67, 129):
         check_against_oracle(ctx, build_scene("random_spheres", count, 3), B.default_params(48, 27, 4))
 
 
