@@ -242,12 +242,13 @@ hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image,
 }
 
 // Every instantiation of the render kernel: (intersect mode, stream layout, primitive kinds, stage).  WIDE8,
-// the throughput mode, has a variant per primitive mix (rectangles only / spheres only / both); SCALAR runs the
-// general one.  Stages 1 and 2 exist for the per-pixel stream layout only.
+// the throughput mode, has a variant per primitive mix (rectangles only / spheres only / at most 64 spheres
+// only / both); SCALAR runs the general one.  Stages 1 and 2 exist for the per-pixel stream layout only.
 #define RT_FOR_EACH_STAGE(X, IM, PR)                                                             \
     X(IM, RT_RNG_ROW_SERIAL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 1) X(IM, RT_RNG_PIXEL, PR, 2)
 #define RT_FOR_EACH_KERNEL(X)                                                                    \
     RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_RECTS) RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_SPHERES) \
+    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_FEW_SPHERES)                              \
     RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_BOTH) RT_FOR_EACH_STAGE(X, RT_INTERSECT_SCALAR, rt::PRIMS_BOTH)
 
 // Lets every render kernel variant use up to `bytes` of dynamic LDS on the current device.  Done once
@@ -269,7 +270,7 @@ hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d
     // the staged scene image, plus one sphere staging slice per wave when the world has spheres
     const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * rt::SPHERE_SLICE_BYTES : 0u);
     const int prims = L.imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
-                      : ctx->sphere_count ? rt::PRIMS_SPHERES : rt::PRIMS_RECTS;
+                      : !ctx->sphere_count ? rt::PRIMS_RECTS : ctx->sphere_count <= 64u ? rt::PRIMS_FEW_SPHERES : rt::PRIMS_SPHERES;
 #define RT_DISPATCH(IM, RM, PR, ST)                                                  \
     if (L.imode == IM && L.rmode == RM && prims == PR && stage == ST)                \
         return launch_variant<IM, RM, PR, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);

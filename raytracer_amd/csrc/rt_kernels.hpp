@@ -52,8 +52,8 @@ struct Workspace {
     uint32_t* pool_count;     // streams deposited by STAGE 1
 };
 constexpr uint32_t POOL_VEC4 = 5;
-// Per-wave LDS slice of worlds with spheres: 64 staged sphere records.
-constexpr uint32_t SPHERE_SLICE_BYTES = 1024u;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
+// Per-wave LDS slice of worlds with spheres: 64 staged sphere records (16 B each), then their 64 tags.
+constexpr uint32_t SPHERE_SLICE_BYTES = 1280u;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
 
 // Diagnostic build only (-DRT_STAMPS, never the shipped library): every wave adds up the shader-clock
 // cycles it spends in each region of the render loop, and a few event counts, and adds them to a global
@@ -103,7 +103,10 @@ struct Stamps {
 // Which primitive loops a kernel variant contains (planes are always there): a world without spheres runs a
 // variant without the sphere code and its registers, and the other way round.  PRIMS_BOTH in WIDE8 mode
 // also orders sphere/rectangle ties by the reference's AVX lane (see intersect_world).
-enum : int { PRIMS_RECTS = 1, PRIMS_SPHERES = 2, PRIMS_BOTH = 3 };
+// PRIMS_FEW_SPHERES: spheres only, at most 64 of them - all records fit the wave's LDS slice, which is then
+// filled once per wave instead of once per ray, and hits read centre and tag from it instead of from global
+// memory; no register set is spent on reading ahead, so more waves fit a SIMD.
+enum : int { PRIMS_RECTS = 1, PRIMS_SPHERES = 2, PRIMS_BOTH = 3, PRIMS_FEW = 4, PRIMS_FEW_SPHERES = PRIMS_SPHERES | PRIMS_FEW };
 
 struct V3 { float x, y, z; };
 
@@ -260,7 +263,7 @@ struct SceneView {
     const float* f;       // LDS image as floats
     const uint32_t* u;    // ... and as words
     const float4* gspheres;   // sphere records (cx cy cz r*r) in the global image
-    float4* wave_spheres;     // this wave's LDS slice: 64 staged sphere records
+    float4* wave_spheres;     // this wave's LDS slice: 64 staged sphere records, then (PRIMS_FEW) their 64 tags
     const uint32_t* gtags;    // sphere tags (material | lane << 24) in the global image
     uint32_t n_planes, n_spheres, n_rects;
     uint32_t off_planes, off_rects, off_mats;
@@ -414,54 +417,79 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
             return (int32_t)(__float_as_uint(d0) & __float_as_uint(d1) & __float_as_uint(d2_) & __float_as_uint(d3)) >= 0;
         };
 
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t chunks = (sv.n_spheres + 63u) / 64u;
-        const uint32_t last = sv.n_spheres - 1u;
-        float4 staged = sv.gspheres[min(lane, last)];
-        for (uint32_t chunk = 0; chunk < chunks; ++chunk) {
-            sv.wave_spheres[lane] = staged;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (chunk + 1 < chunks) staged = sv.gspheres[min(64u * (chunk + 1) + lane, last)];   // next chunk: in flight while this one is tested
-            const uint32_t first = 64u * chunk;
-            const uint32_t count = min(64u, sv.n_spheres - first);
-            const uint32_t groups = count / 4u;
+        if (PRIMS & PRIMS_FEW) {
+            // At most 64 spheres: the kernel's prologue staged all of them in the wave's slice, once.
             const float4* rec = sv.wave_spheres;
-            if (active) {
-            // Groups of four.  The records of the next group are read from LDS before the current group is
-            // worked on, so their latency is covered by arithmetic even with few waves on the SIMD; two
-            // register sets take turns (A, B), so nothing is copied from "next" to "current".
-            auto group = [&](uint32_t g, const float4 s0, const float4 s1, const float4 s2, const float4 s3) {
+            const uint32_t groups = sv.n_spheres / 4u;
+            for (uint32_t g = 0; g < (active ? groups : 0u); ++g) {
+                const float4* r4 = rec + 4u * g;
+                const float4 s0 = r4[0], s1 = r4[1], s2 = r4[2], s3 = r4[3];
                 float b0, b1, b2, b3, c0, c1, c2, c3, e0, e1, e2, e3;
                 terms(s0, b0, c0, e0); terms(s1, b1, c1, e1); terms(s2, b2, c2, e2); terms(s3, b3, c3, e3);
                 if (any_candidate(e0, e1, e2, e3)) {
                     st.mark(ST_SPHERE_TERMS);
-                    roots(first + 4 * g, b0, c0, e0);
-                    roots(first + 4 * g + 1, b1, c1, e1);
-                    roots(first + 4 * g + 2, b2, c2, e2);
-                    roots(first + 4 * g + 3, b3, c3, e3);
+                    roots(4 * g, b0, c0, e0);
+                    roots(4 * g + 1, b1, c1, e1);
+                    roots(4 * g + 2, b2, c2, e2);
+                    roots(4 * g + 3, b3, c3, e3);
                     st.mark(ST_SPHERE_ROOTS);
                 }
-            };
-            float4 a0, a1, a2, a3;
-            if (groups) { a0 = rec[0]; a1 = rec[1]; a2 = rec[2]; a3 = rec[3]; }
-            uint32_t g = 0;
-            for (; g + 2u <= groups; g += 2u) {
-                const float4* nb = rec + 4u * (g + 1u);
-                const float4 b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3];
-                group(g, a0, a1, a2, a3);
-                const float4* na = rec + 4u * min(g + 2u, groups - 1u);
-                a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3];
-                group(g + 1u, b0, b1, b2, b3);
             }
-            if (g < groups) group(g, a0, a1, a2, a3);
-            for (uint32_t k = 4 * groups; k < count; ++k) {
+            for (uint32_t k = 4 * groups; k < (active ? sv.n_spheres : 0u); ++k) {
                 float b, c, disc;
                 terms(rec[k], b, c, disc);
-                roots(first + k, b, c, disc);
+                roots(k, b, c, disc);
             }
+        } else {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t chunks = (sv.n_spheres + 63u) / 64u;
+            const uint32_t last = sv.n_spheres - 1u;
+            float4 staged = sv.gspheres[min(lane, last)];
+            for (uint32_t chunk = 0; chunk < chunks; ++chunk) {
+                sv.wave_spheres[lane] = staged;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (chunk + 1 < chunks) staged = sv.gspheres[min(64u * (chunk + 1) + lane, last)];   // next chunk: in flight while this one is tested
+                const uint32_t first = 64u * chunk;
+                const uint32_t count = min(64u, sv.n_spheres - first);
+                const uint32_t groups = count / 4u;
+                const float4* rec = sv.wave_spheres;
+                if (active) {
+                // Groups of four.  The records of the next group are read from LDS before the current group is
+                // worked on, so their latency is covered by arithmetic even with few waves on the SIMD; two
+                // register sets take turns (A, B), so nothing is copied from "next" to "current".
+                auto group = [&](uint32_t g, const float4 s0, const float4 s1, const float4 s2, const float4 s3) {
+                    float b0, b1, b2, b3, c0, c1, c2, c3, e0, e1, e2, e3;
+                    terms(s0, b0, c0, e0); terms(s1, b1, c1, e1); terms(s2, b2, c2, e2); terms(s3, b3, c3, e3);
+                    if (any_candidate(e0, e1, e2, e3)) {
+                        st.mark(ST_SPHERE_TERMS);
+                        roots(first + 4 * g, b0, c0, e0);
+                        roots(first + 4 * g + 1, b1, c1, e1);
+                        roots(first + 4 * g + 2, b2, c2, e2);
+                        roots(first + 4 * g + 3, b3, c3, e3);
+                        st.mark(ST_SPHERE_ROOTS);
+                    }
+                };
+                float4 a0, a1, a2, a3;
+                if (groups) { a0 = rec[0]; a1 = rec[1]; a2 = rec[2]; a3 = rec[3]; }
+                uint32_t g = 0;
+                for (; g + 2u <= groups; g += 2u) {
+                    const float4* nb = rec + 4u * (g + 1u);
+                    const float4 b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3];
+                    group(g, a0, a1, a2, a3);
+                    const float4* na = rec + 4u * min(g + 2u, groups - 1u);
+                    a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3];
+                    group(g + 1u, b0, b1, b2, b3);
+                }
+                if (g < groups) group(g, a0, a1, a2, a3);
+                for (uint32_t k = 4 * groups; k < count; ++k) {
+                    float b, c, disc;
+                    terms(rec[k], b, c, disc);
+                    roots(first + k, b, c, disc);
+                }
+                }
+                __builtin_amdgcn_wave_barrier();   // the next chunk's store stays behind these reads
             }
-            __builtin_amdgcn_wave_barrier();   // the next chunk's store stays behind these reads
         }
     }
 
@@ -548,7 +576,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
         h.material = sv.u[sv.off_planes + PLANE_WORDS * id + 4];
     } else if ((PRIMS & PRIMS_SPHERES) && (!(PRIMS & PRIMS_RECTS) || id < sv.n_planes + sv.n_spheres)) {
         uint32_t k = id - sv.n_planes;
-        const float4 sp = sv.gspheres[k];
+        const float4 sp = (PRIMS & PRIMS_FEW) ? sv.wave_spheres[k] : sv.gspheres[k];
         V3 c = mk(sp.x, sp.y, sp.z);
         if (IMODE == RT_INTERSECT_WIDE8) {
             // main.cpp:86-87: FMulAdd(d, t, o) - c, scaled by the reciprocal square root of its
@@ -562,7 +590,7 @@ __device__ __forceinline__ Hit resolve_hit(const SceneView& sv, uint32_t best_id
             V3 hp = o + d * t;                 // main.cpp:203-204
             h.normal = normalize(hp - c);
         }
-        h.material = sv.gtags[k] & TAG_MATERIAL_MASK;
+        h.material = ((PRIMS & PRIMS_FEW) ? reinterpret_cast<const uint32_t*>(sv.wave_spheres + 64)[k] : sv.gtags[k]) & TAG_MATERIAL_MASK;
     } else {
         uint32_t k = id - sv.n_planes - sv.n_spheres;
         const float4 tail = *reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * (k >> 1) + 24 + 4 * (k & 1));
@@ -651,6 +679,14 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     sv.gtags = reinterpret_cast<const uint32_t*>(scene_image) + p.sphere_tag_offset;
     sv.off_planes = sv.u[H_OFF_PLANES];
     sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
+    if ((PRIMS & PRIMS_FEW) && sv.n_spheres) {
+        // all records and tags into the wave's slice, once; LDS operations of a wave execute in order
+        const uint32_t lane = threadIdx.x & 63u, k = min(lane, sv.n_spheres - 1u);
+        sv.wave_spheres[lane] = sv.gspheres[k];
+        reinterpret_cast<uint32_t*>(sv.wave_spheres + 64)[lane] = sv.gtags[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     const V3 cam_pos = load3(p.cam_pos), cam_x = load3(p.cam_x), cam_y = load3(p.cam_y);
     const V3 film_center = load3(p.film_center);
