@@ -40,7 +40,7 @@ CONFIGS = {
                     label="spheres + plane (the reference's createScene) 1280x720"),
     "spheres4096": dict(scene=("random_spheres", 4096, 1), width=1920, height=1080, spp=64, bounces=8, lanes=1,
                         label="4096 random spheres + plane 1920x1080"),
-    "glass": dict(scene=("glass_spheres", 5), width=1920, height=1080, spp=512, bounces=32, lanes=4,
+    "glass": dict(scene=("glass_spheres", 5), width=1920, height=1080, spp=512, bounces=32, lanes=8,
                   label="glass-sphere lattice, 32 bounces, 1920x1080"),
 }
 
