@@ -60,7 +60,7 @@ constexpr uint32_t SPHERE_SLICE_BYTES = 1280u;   // sid state samples_left bounc
 // table when it ends.  The stamps cost about a tenth of the run time, so the table is read as shares.
 enum : int { ST_START = 0, ST_CONTROL, ST_PLANES, ST_SPHERE_TERMS, ST_SPHERE_ROOTS, ST_RECTS, ST_RESOLVE, ST_SHADE, ST_EPILOGUE,
              CT_ITERATIONS, CT_LANES_TRACING, CT_ROOTS_BODIES, CT_ROOTS_LANES, CT_START_LANES, CT_HIT_LANES, CT_DIELECTRIC_BODIES,
-             CT_DIELECTRIC_LANES, ST_COUNT };
+             CT_DIELECTRIC_LANES, CT_RECT_PAIRS, CT_RECT_PAIRS_BEHIND, CT_RECTS_OUT_OF_RANGE, CT_RECT_RANGE_LANES, ST_COUNT };
 constexpr int MAX_STAMP_WAVES = 16;
 #ifdef RT_STAMPS
 __device__ unsigned long long rt_stamp_table[ST_COUNT];
@@ -532,6 +532,14 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
             z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
         }
         const F2 t2 = div2(-z_lo, z_ld);   // t = (-origin'.z) / direction'.z for A and B
+#ifdef RT_STAMPS
+        // How often could a wave skip work here?  Pairs whose two planes lie behind every ray of the wave
+        // (t <= 0 on all lanes), and rectangles that no lane's t passes min_hit < t < closest so far.
+        st.count(CT_RECT_PAIRS, 1);
+        st.count(CT_RECT_PAIRS_BEHIND, __ballot(t2.x > 0.0f || t2.y > 0.0f) == 0ull ? 1 : 0);
+        st.count(CT_RECTS_OUT_OF_RANGE, (__ballot(t2.x > min_hit && t2.x < best_t) == 0ull ? 1 : 0) + (__ballot(t2.y > min_hit && t2.y < best_t) == 0ull ? 1 : 0));
+        st.count(CT_RECT_RANGE_LANES, RT_LANES(t2.x > min_hit && t2.x < best_t) + RT_LANES(t2.y > min_hit && t2.y < best_t));
+#endif
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const F2 lo = which ? b_lo : a_lo, ld = which ? b_ld : a_ld;

@@ -16,7 +16,8 @@ from raytracer_amd import binding as B                  # noqa: E402
 from raytracer_amd.host_scene import build_scene        # noqa: E402
 
 NAMES = ["start", "control+normalize", "planes", "sphere terms", "sphere roots", "rects", "resolve hit", "shade", "epilogue",
-         "iterations", "lanes tracing", "roots bodies", "roots lanes", "start lanes", "hit lanes", "dielectric bodies", "dielectric lanes"]
+         "iterations", "lanes tracing", "roots bodies", "roots lanes", "start lanes", "hit lanes", "dielectric bodies", "dielectric lanes",
+         "rect pairs", "rect pairs behind", "rects out of range", "rect range lanes"]
 
 
 def main():
@@ -44,6 +45,11 @@ def main():
         print(f"   start block: {v['start lanes'] / it:.1f} lanes per iteration; hits: {v['hit lanes'] / it:.1f} lanes per iteration")
         if v["roots bodies"]:
             print(f"   sphere roots: {v['roots bodies'] / it:.2f} bodies per iteration with {v['roots lanes'] / v['roots bodies']:.1f} lanes each")
+        if v["rect pairs"]:
+            print(f"   rectangle pairs: {v['rect pairs'] / it:.2f} per iteration; both planes behind every ray of the wave: "
+                  f"{100 * v['rect pairs behind'] / v['rect pairs']:.2f} %; rectangles that no lane's t can improve on "
+                  f"(min_hit < t < closest fails on all lanes): {100 * v['rects out of range'] / (2 * v['rect pairs']):.2f} %, "
+                  f"{v['rect range lanes'] / (2 * v['rect pairs']):.1f} lanes pass it on average")
         if v["dielectric bodies"]:
             print(f"   dielectric block: {v['dielectric bodies'] / it:.2f} per iteration with {v['dielectric lanes'] / v['dielectric bodies']:.1f} lanes each")
 
