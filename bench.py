@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all render on GPU 0 and exchange through gloo + host copies: exercises the multi-rank path "
                          "where only one GPU exists; its throughput means nothing")
+    ap.add_argument("--through-process-group", action="store_true",
+                    help="with one rank under torch.distributed.run: run the multi-rank code path (process group, gather, fixed-order sum) anyway")
     ap.add_argument("--cpu-spp", type=int, default=-1, help="spp of the bounded CPU-baseline sample (0 = skip, -1 = sized for ~10 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every online core, as the reference does)")
     return ap.parse_args()
@@ -152,7 +154,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world_size
-    distributed = world_size > 1
+    # --through-process-group (under a launcher): also a one-rank job goes through the process group, so that
+    # a one-GPU box exercises the RCCL calls of the N-GPU job.
+    distributed = world_size > 1 or (args.through_process_group and "RANK" in os.environ)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -327,7 +331,7 @@ def main():
         if composition is not None:
             composition["rays_identical"] = composition.pop("one_gpu_rays") == total_rays // max(args.steps, 1)
             line["composition_check"] = composition
-        if world_size == 1:
+        if world_size == 1 and not distributed:
             line["cpu_baseline"] = cpu_baseline(W if args.config.startswith("cornell") else 1920, H if args.config.startswith("cornell") else 1080,
                                                 args.cpu_spp, args.cpu_threads)
         print(json.dumps(line), flush=True)

@@ -92,11 +92,13 @@ class RowShardedImage:
         self._source_rows = None
 
     def gather(self):
-        if self.world_size > 1 and self.shard.is_cuda and _host_staged():
+        # With a process group the collective runs even for a single rank (it is then a copy by the transport:
+        # a one-rank launch exercises the same calls as an N-rank one); without one the shard is the image.
+        if dist.is_initialized() and self.shard.is_cuda and _host_staged():
             flat = torch.zeros(self._gathered_flat.shape, dtype=self.shard.dtype)
             dist.all_gather_into_tensor(flat, self.shard.cpu())
             self._gathered_flat.copy_(flat)
-        elif self.world_size > 1:
+        elif dist.is_initialized():
             dist.all_gather_into_tensor(self._gathered_flat, self.shard)
         else:
             self.gathered[0].copy_(self.shard)
@@ -125,7 +127,7 @@ class GatheredSums:
 
     def gather(self, radiance_sum: torch.Tensor):
         """Collects every rank's sum on rank 0 (one gather; nothing is added in transit)."""
-        if self.world_size == 1:
+        if not dist.is_initialized():
             self.parts[0].copy_(radiance_sum)
         elif radiance_sum.is_cuda and _host_staged():
             mine = radiance_sum.cpu()

@@ -78,3 +78,22 @@ def test_processes_compose_the_single_gpu_image(tmp_path, world_size):
     assert int(out["sample_rays"][0]) == rays_all
     assert np.array_equal(out["sample_pixels"], pix_all)
     ctx.close()
+
+
+@pytest.mark.parametrize("shard", ["samples", "rows"])
+def test_bench_through_rccl_with_one_rank(shard):
+    """bench.py's multi-rank path on the real transport: one rank under torch.distributed.run, process group on
+    the GPU (backend "nccl" = RCCL), gather / all_gather of device tensors, fixed-order sum, resolve; the
+    composed image and ray count equal a plain render of the job."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--through-process-group", "--shard", shard, "--cpu-spp", "0", "--width", "480", "--height", "270"]
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True, timeout=240).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["shard"] == shard
+    assert line["composition_check"] == {"pixels_identical_to_one_gpu_render": True, "rays_identical": True}
