@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all render on GPU 0 and exchange through gloo + host copies: exercises the multi-rank path "
                          "where only one GPU exists; its throughput means nothing")
+    ap.add_argument("--no-overlap", action="store_true", help="samples mode: gather and sum each step before the next one starts")
     ap.add_argument("--through-process-group", action="store_true",
                     help="with one rank under torch.distributed.run: run the multi-rank code path (process group, gather, fixed-order sum) anyway")
     ap.add_argument("--cpu-spp", type=int, default=-1, help="spp of the bounded CPU-baseline sample (0 = skip, -1 = sized for ~10 s)")
@@ -200,13 +201,32 @@ def main():
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
 
+    # samples mode: the gather of step i travels (on RCCL's stream) while step i + 1 renders into the other
+    # buffer; rank 0 adds and resolves step i after step i + 1 has been enqueued.  drain() completes the last one.
+    overlap = distributed and not rows_mode and not args.no_overlap
+    buffers = [radiance, torch.zeros_like(radiance)] if overlap else [radiance]
+    combined = torch.zeros_like(radiance) if distributed and not rows_mode and rank == 0 else None   # rank 0: sum over the ranks
+    in_flight = []      # at most one (handle) of a gather that has been started and not yet combined
+
+    def combine_on_rank_0():
+        if rank == 0:
+            # fixed pairwise tree over the ranks, then color / sampleSize + pack (main.cpp:393)
+            ctx.combine_device(gathered.parts.data_ptr(), world_size, H * W * 3, H * W * 3, combined.data_ptr(), stream.cuda_stream)
+            ctx.resolve_device(combined.data_ptr(), W * H, spp * world_size, pixels.data_ptr(), None, stream.cuda_stream)
+
+    def drain():
+        while in_flight:
+            gathered.finish(in_flight.pop())
+            combine_on_rank_0()
+
     def step(i):
         d_rays = rays.data_ptr() + 8 * i
         starts[i].record(stream)
         if rows_mode:
             ctx.render_device(p, sharded.shard.data_ptr(), None, d_rays, stream.cuda_stream)
         elif distributed:
-            ctx.render_device(p, None, radiance.data_ptr(), d_rays, stream.cuda_stream)
+            target = buffers[i % len(buffers)]
+            ctx.render_device(p, None, target.data_ptr(), d_rays, stream.cuda_stream)
         else:
             ctx.render_device(p, pixels.data_ptr(), None, d_rays, stream.cuda_stream)
         stops[i].record(stream)
@@ -215,13 +235,13 @@ def main():
             if rank == 0:
                 sharded.assemble(out=pixels)
         elif distributed:
-            gathered.gather(radiance)
-            if rank == 0:
-                # fixed pairwise tree over the ranks, then color / sampleSize + pack (main.cpp:393)
-                ctx.combine_device(gathered.parts.data_ptr(), world_size, H * W * 3, H * W * 3, radiance.data_ptr(), stream.cuda_stream)
-                ctx.resolve_device(radiance.data_ptr(), W * H, spp * world_size, pixels.data_ptr(), None, stream.cuda_stream)
+            drain()                                   # the previous step's sums: arrived while this step rendered
+            in_flight.append(gathered.start(target))
+            if not overlap:
+                drain()
 
     def fence():
+        drain()
         torch.cuda.synchronize(device)
         if distributed:
             dist.barrier()

@@ -127,9 +127,17 @@ class GatheredSums:
 
     def gather(self, radiance_sum: torch.Tensor):
         """Collects every rank's sum on rank 0 (one gather; nothing is added in transit)."""
+        self.finish(self.start(radiance_sum))
+
+    def start(self, radiance_sum: torch.Tensor):
+        """Begins the gather of `radiance_sum` and returns a handle for finish().  On RCCL the transfer runs on
+        the transport's own stream, ordered after everything enqueued so far on the current stream, and the
+        current stream is free to go on (the next render) until finish(); `radiance_sum` must not be written
+        and `parts` not read in between.  Host-staged groups (gloo) and single processes complete here."""
         if not dist.is_initialized():
             self.parts[0].copy_(radiance_sum)
-        elif radiance_sum.is_cuda and _host_staged():
+            return None
+        if radiance_sum.is_cuda and _host_staged():
             mine = radiance_sum.cpu()
             if self.rank == 0:
                 received = [torch.zeros_like(mine) for _ in range(self.world_size)]
@@ -138,10 +146,14 @@ class GatheredSums:
                     self.parts[r].copy_(received[r])
             else:
                 dist.gather(mine, gather_list=None, dst=0)
-        elif self.rank == 0:
-            dist.gather(radiance_sum, gather_list=[self.parts[r] for r in range(self.world_size)], dst=0)
-        else:
-            dist.gather(radiance_sum, gather_list=None, dst=0)
+            return None
+        gather_list = [self.parts[r] for r in range(self.world_size)] if self.rank == 0 else None
+        return dist.gather(radiance_sum, gather_list=gather_list, dst=0, async_op=True)
+
+    def finish(self, handle):
+        """Makes the current stream wait for the gather begun by start() (the host does not block on RCCL)."""
+        if handle is not None:
+            handle.wait()
 
 
 def tree_order_sum(parts: torch.Tensor) -> torch.Tensor:
