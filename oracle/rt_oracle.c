@@ -429,10 +429,103 @@ static int intersect_wide(const rto_scene* s, int ieee_rsqrt, float min_hit, flo
     return any_hit;
 }
 
+/* The same routine for any lane width (simd.h:17 fixes LANE_WIDTH at 8; its 4-wide branch, simd_sse.h, has
+ * the same operations: fused FMulAdd / FMulSub under __FMA__, _mm_rsqrt_ps).  Primitive k lives in lane
+ * k % L of group k / L (scene.h:255-286, 414-447); each lane keeps its own running closest hit and the
+ * first strictly smaller lane wins at the end (main.cpp:131-154).  With L = 8 this is intersect_wide
+ * reading the records in place (a test holds the two equal); L = 4 restates a LANE_WIDTH 4 build, which
+ * cannot be produced from the reference without editing simd.h: PARITY UNPINNED for ties between lanes. */
+static int intersect_wide_lanes(const rto_scene* s, uint32_t L, int ieee_rsqrt, float min_hit, float plane_tol, v3 o, v3 d,
+                                float* t_out, uint32_t* mat_out, v3* n_out) {
+    float closest = FLT_MAX;
+    uint32_t hit_mat = 0;
+    v3 hit_n = V(0, 0, 0);
+    int any_hit = 0;
+    for (uint32_t i = 0; i < s->plane_count; ++i) {
+        const rto_plane* pl = &s->planes[i];
+        v3 n = from3(pl->normal);
+        float denom = vdot(n, d);
+        if ((denom < -plane_tol) || (denom > plane_tol)) {
+            float hit = (-pl->d - vdot(n, o)) / denom;
+            if (hit > min_hit && hit < closest) { closest = hit; hit_mat = pl->material_index; hit_n = n; any_hit = 1; }
+        }
+    }
+    float lane_t[LANES], lane_mat[LANES], lane_nx[LANES], lane_ny[LANES], lane_nz[LANES];
+    for (uint32_t j = 0; j < L; ++j) {
+        lane_t[j] = closest; lane_mat[j] = (float)hit_mat;
+        lane_nx[j] = hit_n.x; lane_ny[j] = hit_n.y; lane_nz[j] = hit_n.z;
+    }
+    for (uint32_t k = 0; k < s->sphere_count; ++k) {      /* group k / L, lane k % L: groups in order, lanes independent */
+        const rto_sphere* sp = &s->spheres[k];
+        const uint32_t j = k % L;
+        float cx = sp->position[0], cy = sp->position[1], cz = sp->position[2];
+        float r2 = sp->radius * sp->radius;
+        float tx = o.x - cx, ty = o.y - cy, tz = o.z - cz;
+        float a = lane_dot3(d.x, d.y, d.z, d.x, d.y, d.z);
+        float b = 2.0f * lane_dot3(d.x, d.y, d.z, tx, ty, tz);
+        float c = lane_dot3(tx, ty, tz, tx, ty, tz) - r2;
+        float disc = fmaf(b, b, -(4.0f * a * c));
+        float denom = 2.0f * a;
+        if (!(disc > 0.0f)) continue;
+        float root = sqrtf(disc);
+        float tp = (-b + root) / denom;
+        float tn = (-b - root) / denom;
+        float hit = tp;
+        if (tn > min_hit && tn < tp) hit = tn;
+        if (hit > min_hit && hit < lane_t[j]) {
+            lane_t[j] = hit;
+            lane_mat[j] = (float)sp->material_index;
+            float hx = fmaf(d.x, hit, o.x), hy = fmaf(d.y, hit, o.y), hz = fmaf(d.z, hit, o.z);
+            float vx = hx - cx, vy = hy - cy, vz = hz - cz;
+            float len2 = lane_dot3(vx, vy, vz, vx, vy, vz);
+            float f = ieee_rsqrt ? 1.0f / sqrtf(len2) : hw_rsqrt(len2);
+            lane_nx[j] = vx * f; lane_ny[j] = vy * f; lane_nz[j] = vz * f;
+            any_hit = 1;
+        }
+    }
+    for (uint32_t k = 0; k < s->rectangle_count; ++k) {
+        const rto_rectangle* r = &s->rectangles[k];
+        const uint32_t j = k % L;
+        float lo[3], ld[3];
+        for (int row = 0; row < 3; ++row) {
+            lo[row] = lane_dot4(r->m[row][0], r->m[row][1], r->m[row][2], r->m[row][3], o.x, o.y, o.z, 1.0f);
+            ld[row] = lane_dot4(r->m[row][0], r->m[row][1], r->m[row][2], r->m[row][3], d.x, d.y, d.z, 0.0f);
+        }
+        float t = (-lo[2]) / ld[2];
+        float hx = lo[0] + ld[0] * t;
+        float hy = lo[1] + ld[1] * t;
+        int hit = hx <= 1.0f && hx >= -1.0f && hy <= 1.0f && hy >= -1.0f;
+        if (hit && t < lane_t[j] && t > min_hit) {
+            lane_t[j] = t;
+            lane_mat[j] = (float)r->material_index;
+            float nx = r->normal[0], ny = r->normal[1], nz = r->normal[2];
+            float dot = lane_dot3(nx, ny, nz, d.x, d.y, d.z);
+            if (dot > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+            lane_nx[j] = nx; lane_ny[j] = ny; lane_nz[j] = nz;
+            any_hit = 1;
+        }
+    }
+    if (any_hit) {
+        for (uint32_t j = 0; j < L; ++j) {
+            float t = lane_t[j];
+            if (t < closest) {
+                closest = t;
+                hit_mat = (uint32_t)lane_mat[j];
+                hit_n = V(lane_nx[j], lane_ny[j], lane_nz[j]);
+            }
+        }
+    }
+    *t_out = closest; *mat_out = hit_mat; *n_out = hit_n;
+    return any_hit;
+}
+
 static inline int intersect(const rto_scene* s, int mode, float min_hit, float plane_tol, v3 o, v3 d,
                             float* t, uint32_t* mat, v3* n) {
     if (mode == RTO_INTERSECT_SCALAR) return intersect_scalar(s, min_hit, plane_tol, o, d, t, mat, n);
     if (mode == RTO_INTERSECT_WIDE8_AVX2) return rto_intersect_wide_avx2(s, min_hit, plane_tol, o, d, t, mat, n);
+    if (mode == RTO_INTERSECT_WIDE4 || mode == RTO_INTERSECT_WIDE4_IEEE)
+        return intersect_wide_lanes(s, 4, mode == RTO_INTERSECT_WIDE4_IEEE, min_hit, plane_tol, o, d, t, mat, n);
+    if (mode == RTO_INTERSECT_WIDE8_LANES) return intersect_wide_lanes(s, 8, 0, min_hit, plane_tol, o, d, t, mat, n);
     return intersect_wide(s, mode == RTO_INTERSECT_WIDE8_IEEE, min_hit, plane_tol, o, d, t, mat, n);
 }
 

@@ -44,7 +44,11 @@ typedef struct rto_scene rto_scene;
  * (simd_avx2.h:139-144; hardware specific, relative error <= 1.5 * 2^-12).  WIDE8_IEEE uses the
  * correctly rounded 1/sqrtf instead and is otherwise identical: it is what the HIP kernels compute,
  * since no GPU instruction reproduces the x86 approximation. */
-enum { RTO_INTERSECT_WIDE8 = 0, RTO_INTERSECT_SCALAR = 1, RTO_INTERSECT_WIDE8_AVX2 = 2, RTO_INTERSECT_WIDE8_IEEE = 3 };
+enum { RTO_INTERSECT_WIDE8 = 0, RTO_INTERSECT_SCALAR = 1, RTO_INTERSECT_WIDE8_AVX2 = 2, RTO_INTERSECT_WIDE8_IEEE = 3,
+       /* LANE_WIDTH 4 (simd.h:17-26, simd_sse.h): same arithmetic, primitives dealt to 4 lanes.  The reference cannot
+        * be built at that width without editing simd.h, so these two are PARITY UNPINNED where lanes tie.
+        * WIDE8_LANES: the width-generic routine at width 8 (a test holds it equal to WIDE8). */
+       RTO_INTERSECT_WIDE4 = 4, RTO_INTERSECT_WIDE4_IEEE = 5, RTO_INTERSECT_WIDE8_LANES = 6 };
 enum { RTO_RNG_ROW_SERIAL = 0, RTO_RNG_PIXEL = 1 };
 
 typedef struct {

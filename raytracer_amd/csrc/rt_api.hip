@@ -37,10 +37,10 @@ struct rt_context {
     bool has_world = false;
     bool mixed = false;             // spheres and rectangles both present
     rt_camera camera{};
-    uint32_t image_words[2] = {0, 0};
+    uint32_t image_words[3] = {0, 0, 0};
     uint32_t lds_words = 0;                 // part of the image each workgroup stages in LDS (same for both images)
     uint32_t sphere_count = 0, sphere_offset = 0, sphere_tag_offset = 0;
-    uint4* d_image[2] = {nullptr, nullptr};
+    uint4* d_image[3] = {nullptr, nullptr, nullptr};   // indexed by RT_INTERSECT_*
 
     // buffers behind rt_render (host outputs); grow-only
     uint32_t* d_pixels = nullptr;
@@ -124,7 +124,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "band_index %u / band_count %u invalid", p->band_index, p->band_count);
     if (p->rng_mode != RT_RNG_ROW_SERIAL && p->rng_mode != RT_RNG_PIXEL)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown rng_mode %u", p->rng_mode);
-    if (p->intersect_mode != RT_INTERSECT_WIDE8 && p->intersect_mode != RT_INTERSECT_SCALAR)
+    if (p->intersect_mode != RT_INTERSECT_WIDE8 && p->intersect_mode != RT_INTERSECT_SCALAR && p->intersect_mode != RT_INTERSECT_WIDE4)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown intersect_mode %u", p->intersect_mode);
     if (!(p->min_hit_distance >= 0.0f) || !(p->plane_tolerance >= 0.0f))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "min_hit_distance and plane_tolerance must be >= 0");
@@ -269,10 +269,12 @@ hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d
     const uint4* image = ctx->d_image[L.imode];
     // the staged scene image, plus one sphere staging slice per wave when the world has spheres
     const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * rt::SPHERE_SLICE_BYTES : 0u);
-    const int prims = L.imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
+    // RT_INTERSECT_WIDE4 is the wide routine on an image whose primitives are dealt to four lanes: same kernels.
+    const int kernel_imode = L.imode == RT_INTERSECT_WIDE4 ? RT_INTERSECT_WIDE8 : L.imode;
+    const int prims = kernel_imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
                       : !ctx->sphere_count ? rt::PRIMS_RECTS : ctx->sphere_count <= 64u ? rt::PRIMS_FEW_SPHERES : rt::PRIMS_SPHERES;
 #define RT_DISPATCH(IM, RM, PR, ST)                                                  \
-    if (L.imode == IM && L.rmode == RM && prims == PR && stage == ST)                \
+    if (kernel_imode == IM && L.rmode == RM && prims == PR && stage == ST)           \
         return launch_variant<IM, RM, PR, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);
     RT_FOR_EACH_KERNEL(RT_DISPATCH)
 #undef RT_DISPATCH
@@ -548,7 +550,7 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
 void rt_destroy(rt_context* ctx) {
     if (!ctx) return;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
     if (ctx->d_pixels) (void)hipFree(ctx->d_pixels);
     if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
@@ -656,17 +658,17 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
 
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t lds_limit = ctx->props.sharedMemPerBlockOptin ? ctx->props.sharedMemPerBlockOptin : ctx->props.sharedMemPerBlock;
-    std::vector<uint32_t> images[2] = {rt::pack_scene_image(*w, true), rt::pack_scene_image(*w, false)};
+    std::vector<uint32_t> images[3] = {rt::pack_scene_image(*w, 8), rt::pack_scene_image(*w, 0), rt::pack_scene_image(*w, 4)};
     // a world with spheres also needs the waves' sphere staging slices, at most 16 waves per workgroup
     const size_t staging = w->sphere_count ? 16u * rt::SPHERE_SLICE_BYTES : 0u;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if ((size_t)images[i][rt::H_LDS_WORDS] * 4 + staging > lds_limit)
             return fail(ctx, RT_ERR_TOO_LARGE, "planes, rectangles and materials take %zu bytes, the LDS of one workgroup holds %zu",
                         (size_t)images[i][rt::H_LDS_WORDS] * 4 + staging, lds_limit);
-    // Both new images are allocated and filled before the context is touched, so a failure leaves the
+    // The new images are allocated and filled before the context is touched, so a failure leaves the
     // previous world in place and usable.
-    uint4* fresh[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; ++i) {
+    uint4* fresh[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
         hipError_t e = hipMalloc(&fresh[i], images[i].size() * 4);
         if (e == hipSuccess) e = hipMemcpy(fresh[i], images[i].data(), images[i].size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -676,7 +678,7 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
         }
     }
     RT_HIP_CHECK(ctx, hipDeviceSynchronize());   // no render may still read the old images
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
         ctx->d_image[i] = fresh[i];
         ctx->image_words[i] = (uint32_t)images[i].size();

@@ -48,22 +48,25 @@ enum : uint32_t {
 };
 
 constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_PAIR_WORDS = 40, MAT_WORDS = 12;
-constexpr uint32_t WIDE_LANES = 8;        // simd.h:17
+constexpr uint32_t WIDE_LANES = 8;        // simd.h:17; the SSE branch of simd.h:20-26 is 4 wide (RT_INTERSECT_WIDE4)
 constexpr uint32_t TAG_LANE_SHIFT = 24;   // tag = material | lane << 24
 constexpr uint32_t TAG_MATERIAL_MASK = 0x00FFFFFFu;
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
-// Indices 0..n-1 sorted by (i % 8, i / 8).
-inline std::vector<uint32_t> wide_order(uint32_t n) {
+// Indices 0..n-1 sorted by (i % lanes, i / lanes).
+inline std::vector<uint32_t> wide_order(uint32_t n, uint32_t lanes) {
     std::vector<uint32_t> order;
     order.reserve(n);
-    for (uint32_t j = 0; j < WIDE_LANES; ++j)
-        for (uint32_t i = j; i < n; i += WIDE_LANES) order.push_back(i);
+    for (uint32_t j = 0; j < lanes; ++j)
+        for (uint32_t i = j; i < n; i += lanes) order.push_back(i);
     return order;
 }
 
-inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
+// wide_lanes: 0 = the scalar routine's image (index order, unfused arithmetic for the camera rows), else the
+// lane width of the wide routine (8, or 4 for a LANE_WIDTH 4 build).
+inline std::vector<uint32_t> pack_scene_image(const rt_world& w, uint32_t wide_lanes) {
+    const bool wide = wide_lanes != 0;
     auto round4 = [](uint32_t v) { return (v + 3u) & ~3u; };
     uint32_t off_planes = H_WORDS;
     uint32_t off_rects = off_planes + PLANE_WORDS * w.plane_count;
@@ -87,17 +90,17 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
         q[4] = p.material_index;
     }
 
-    std::vector<uint32_t> sphere_order = wide ? wide_order(w.sphere_count) : std::vector<uint32_t>();
+    std::vector<uint32_t> sphere_order = wide ? wide_order(w.sphere_count, wide_lanes) : std::vector<uint32_t>();
     for (uint32_t k = 0; k < w.sphere_count; ++k) {
         uint32_t i = wide ? sphere_order[k] : k;
         const rt_sphere& s = w.spheres[i];
         uint32_t* q = &img[off_spheres + SPHERE_WORDS * k];
         q[0] = f2u(s.position[0]); q[1] = f2u(s.position[1]); q[2] = f2u(s.position[2]);
         q[3] = f2u(s.radius * s.radius);   // scene.h:274 / main.cpp:187: rounded once, then used
-        img[off_tags + k] = s.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
+        img[off_tags + k] = s.material_index | ((wide ? i % wide_lanes : 0u) << TAG_LANE_SHIFT);
     }
 
-    std::vector<uint32_t> rect_order = wide ? wide_order(w.rectangle_count) : std::vector<uint32_t>();
+    std::vector<uint32_t> rect_order = wide ? wide_order(w.rectangle_count, wide_lanes) : std::vector<uint32_t>();
     for (uint32_t k = 0; k < w.rectangle_count; ++k) {
         uint32_t i = wide ? rect_order[k] : k;
         const rt_rectangle& r = w.rectangles[i];
@@ -124,7 +127,7 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, bool wide) {
         }
         uint32_t* tail = q + 24 + 4 * which;
         tail[0] = f2u(r.normal[0]); tail[1] = f2u(r.normal[1]); tail[2] = f2u(r.normal[2]);
-        tail[3] = r.material_index | ((wide ? i % WIDE_LANES : 0u) << TAG_LANE_SHIFT);
+        tail[3] = r.material_index | ((wide ? i % wide_lanes : 0u) << TAG_LANE_SHIFT);
     }
 
     for (uint32_t i = 0; i < w.material_count; ++i) {

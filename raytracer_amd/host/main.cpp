@@ -45,7 +45,7 @@ void Usage() {
     std::fprintf(stderr,
                  "usage: raytracer [--scene cornell|spheres|random_spheres|glass_spheres|FILE.rtsc] [--count N] [--scene-seed S]\n"
                  "                 [--width W] [--height H] [--spp N] [--bounces N] [--seed-constant N]\n"
-                 "                 [--rng pixel|row] [--lanes-per-pixel N] [--compact] [--intersect wide|scalar]\n"
+                 "                 [--rng pixel|row] [--lanes-per-pixel N] [--compact] [--intersect wide|wide4|scalar]\n"
                  "                 [--gpus N | --devices 0,1,...] [--out FILE.bmp]\n"
                  "                 [--passes N] [--checkpoint FILE.rtfb] [--resume FILE.rtfb]\n");
 }
@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
     params.rng_mode = opt.rng == "row" ? RT_RNG_ROW_SERIAL : RT_RNG_PIXEL;
     params.lanes_per_pixel = opt.lanes_per_pixel;
     if (opt.compact) params.flags |= RT_FLAG_COMPACT_TAILS;
-    params.intersect_mode = opt.intersect == "scalar" ? RT_INTERSECT_SCALAR : RT_INTERSECT_WIDE8;
+    params.intersect_mode = opt.intersect == "scalar" ? RT_INTERSECT_SCALAR : opt.intersect == "wide4" ? RT_INTERSECT_WIDE4 : RT_INTERSECT_WIDE8;
 
     // The render: interleaved 8-row bands, one host thread per GPU, assembled in image.pixelData.
     auto start = std::chrono::steady_clock::now();

@@ -14,7 +14,7 @@ import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 LIB_PATH = ROOT / "oracle" / "librt_oracle.so"
 
-WIDE8, SCALAR, WIDE8_AVX2, WIDE8_IEEE = 0, 1, 2, 3
+WIDE8, SCALAR, WIDE8_AVX2, WIDE8_IEEE, WIDE4, WIDE4_IEEE, WIDE8_LANES = 0, 1, 2, 3, 4, 5, 6
 ROW_SERIAL, PIXEL = 0, 1
 
 

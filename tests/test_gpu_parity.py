@@ -21,7 +21,7 @@ from raytracer_amd.host_scene import build_scene
 
 pytestmark = pytest.mark.gpu
 
-ORACLE_MODE = {B.INTERSECT_WIDE8: O.WIDE8_IEEE, B.INTERSECT_SCALAR: O.SCALAR}
+ORACLE_MODE = {B.INTERSECT_WIDE8: O.WIDE8_IEEE, B.INTERSECT_SCALAR: O.SCALAR, B.INTERSECT_WIDE4: O.WIDE4_IEEE}
 
 
 @pytest.fixture(scope="module")
@@ -523,7 +523,7 @@ def test_random_scenes_bit_exact(ctx, seed):
     scene = _random_scene(rng)
     w, h, spp = int(rng.integers(17, 70)), int(rng.integers(9, 40)), int(rng.choice([4, 8, 16]))
     bounces = int(rng.choice([2, 8, 8, 20]))
-    for imode in (B.INTERSECT_WIDE8, B.INTERSECT_SCALAR):
+    for imode in (B.INTERSECT_WIDE8, B.INTERSECT_SCALAR, B.INTERSECT_WIDE4):
         check_against_oracle(ctx, scene, B.default_params(w, h, spp, intersect_mode=imode, max_bounces=bounces,
                                                           lanes_per_pixel=int(rng.choice([1, 2, 4]))))
         check_against_oracle(ctx, scene, B.default_params(w, h, spp, intersect_mode=imode, max_bounces=bounces,
@@ -532,6 +532,47 @@ def test_random_scenes_bit_exact(ctx, seed):
     lanes = int(rng.choice([1, 2, 4]))
     check_against_oracle(ctx, scene, B.default_params(w, h, 64 * lanes, max_bounces=bounces, lanes_per_pixel=lanes,
                                                       flags=B.FLAG_COMPACT_TAILS))
+
+
+def tie_scene():
+    """Five coplanar unit rectangles on top of each other (z = 0, facing the camera; a sixth, index 0, behind them),
+    each with its own emissive material: every primary ray meets the five at exactly the same t, so the winner is
+    decided by the order of the routine alone - index order in the scalar routine, (lane, group) order at lane
+    width 8 or 4."""
+    mats = np.zeros(8, dtype=scene_io.MATERIAL)
+    mats["emit_color"][0] = (0.1, 0.1, 0.1)
+    for i in range(1, 8):
+        mats["emit_color"][i] = (i & 1, (i >> 1) & 1, (i >> 2) & 1)
+    rects = np.zeros(6, dtype=scene_io.RECTANGLE)
+    for i, r in enumerate(rects):
+        r["inverse_transform"] = np.eye(4, dtype=np.float32)
+        r["normal"] = (0, 0, 1)
+        r["material_index"] = 1 + i
+    rects["inverse_transform"][0][2, 3] = 0.5      # index 0 lies half a unit behind the others: it never wins
+    # a seventh one in front of the right half only, so that lanes also have to yield to a strictly closer hit
+    front = np.zeros(1, dtype=scene_io.RECTANGLE)
+    m = np.eye(4); m[0, 0] = 0.5; m[0, 3] = 0.5; m[2, 3] = 0.25
+    front["inverse_transform"][0] = np.linalg.inv(m).astype(np.float32)
+    front["normal"][0] = (0, 0, 1)
+    front["material_index"][0] = 7
+    rects = np.concatenate([rects[:5], front, rects[5:]])
+    cam = np.zeros(1, dtype=scene_io.CAMERA)
+    cam["position"], cam["z_axis"], cam["y_axis"], cam["x_axis"] = (0, 0, 3), (0, 0, 1), (0, 1, 0), (1, 0, 0)
+    return scene_io.Scene(mats, np.zeros(0, dtype=scene_io.PLANE), np.zeros(0, dtype=scene_io.SPHERE), rects, cam)
+
+
+def test_ties_between_primitives_follow_the_lane_order(ctx):
+    """Exact ties in t: each routine's winner is its oracle's (scalar: lowest index; wide: lowest lane, then lowest
+    group, at width 8 and at width 4), and the three orders really give three different images here."""
+    scene = tie_scene()
+    images = {}
+    for imode in (B.INTERSECT_SCALAR, B.INTERSECT_WIDE8, B.INTERSECT_WIDE4):
+        _, rad, _ = check_against_oracle(ctx, scene, B.default_params(64, 36, 4, intersect_mode=imode, max_bounces=2))
+        images[imode] = rad
+    # 7 rectangles: width 8 keeps every primitive in its own lane (= index order, like the scalar routine: index 1
+    # wins); at width 4 index 4 shares lane 0 with the farther index 0, replaces it there, and lane 0 goes first
+    assert np.array_equal(images[B.INTERSECT_SCALAR], images[B.INTERSECT_WIDE8])
+    assert not np.array_equal(images[B.INTERSECT_WIDE4], images[B.INTERSECT_WIDE8])
 
 
 # ---------------------------------------------------------------- sums, passes and their composition, against the oracle
