@@ -3,13 +3,12 @@
 //
 // One image per intersection mode, each self-contained (header + sections).  The first
 // H_LDS_WORDS words (header, planes, rectangles, materials) are staged in LDS by every
-// workgroup with a flat 16-byte copy; the sphere records stay in global memory and are
-// fetched through the scalar cache (every lane of a wave tests the same sphere, so one
-// s_load_dwordx16 brings four of them into scalar registers for all 64 lanes).
+// workgroup with a flat 16-byte copy; the sphere records stay in global memory, from where
+// every wave copies them, 64 at a time, into its own LDS slice (rt_kernels.hpp, intersect_world).
 //
 //   header   16 words  counts and section offsets (in words)
 //   planes    8 words  nx ny nz d | material 0 0 0
-//   rects    40 words per PAIR of rectangles (A, B), laid out for packed-FP32 arithmetic:
+//   rects    40 words per PAIR of rectangles (A, B), the two handled side by side:
 //              A.r0x A.r1x A.r0y A.r1y | A.r0z A.r1z A.r0w A.r1w      rows 0,1 of A's inverse transform, interleaved
 //              B.r0x B.r1x B.r0y B.r1y | B.r0z B.r1z B.r0w B.r1w      same for B
 //              A.r2x B.r2x A.r2y B.r2y | A.r2z B.r2z A.r2w B.r2w      row 2 of A and of B, interleaved
