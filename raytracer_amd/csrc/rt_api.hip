@@ -88,13 +88,22 @@ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 // bound keeps the handed-over streams short: stage 2 only begins when stage 1 has ended, so a long stream
 // would run there on its own (measured on the Cornell bench without it: stage 1 -1.1 ms, stage 2 +1.6 ms).
 // Defaults from a sweep on the bench (T 16..48 x S 2..32); the environment variables are for experiments.
+// A lane with few samples hands over at most a quarter of them: the bound is min(12, samples_per_lane / 4 - 1),
+// and renders with fewer than 8 samples per lane run as one launch (4096 spheres at 64 spp: 4 lanes per pixel
+// with 16 samples each and a bound of 3 take 498 ms, one lane per pixel with the bound of 12 takes 566 ms).
 uint32_t env_or(const char* name, long fallback, long lo, long hi) {
     const char* env = std::getenv(name);
     long v = env ? std::strtol(env, nullptr, 10) : fallback;
     return (uint32_t)(v < lo ? lo : v > hi ? hi : v);
 }
 uint32_t pool_threshold() { static const uint32_t v = env_or("RT_POOL_THRESHOLD", 32, 1, 63); return v; }
-uint32_t pool_max_samples() { static const uint32_t v = env_or("RT_POOL_MAX_SAMPLES", 12, 0, 1 << 20); return v; }
+constexpr uint32_t MIN_SAMPLES_PER_LANE_TO_COMPACT = 8;
+uint32_t pool_max_samples(uint32_t samples_per_lane) {
+    static const uint32_t forced = env_or("RT_POOL_MAX_SAMPLES", -1, -1, 1 << 20);
+    if (forced != (uint32_t)-1) return forced;
+    const uint32_t quarter = samples_per_lane / 4u;
+    return quarter ? (quarter - 1u < 12u ? quarter - 1u : 12u) : 0u;
+}
 
 struct Launch {
     rt::KernelParams kp;
@@ -178,7 +187,8 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         k.rows_per_order = 1; k.order_count = 0;
         lanes = (uint64_t)k.tiles_x * k.tiles_y * 64;
         // worth it only when a lane's samples are many compared with what may be handed over
-        out->compact = (p->flags & RT_FLAG_COMPACT_TAILS) != 0 && k.samples_per_lane >= 4 * (pool_max_samples() + 1);
+        out->compact = (p->flags & RT_FLAG_COMPACT_TAILS) != 0 && k.samples_per_lane >= MIN_SAMPLES_PER_LANE_TO_COMPACT &&
+                       k.samples_per_lane >= 4 * (pool_max_samples(k.samples_per_lane) + 1);
     }
     // A CU has 160 KB of LDS and room for 2048 threads: pick the workgroup size so that the LDS
     // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
@@ -198,7 +208,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     if (out->compact) {
         // A stage-1 wave hands over at most pool_threshold streams, so waves * threshold entries always suffice.
         k.pool_threshold = pool_threshold();
-        k.pool_max_samples = pool_max_samples();
+        k.pool_max_samples = pool_max_samples(k.samples_per_lane);
         const uint64_t waves = blocks * (out->block_threads / 64u);
         if (max_pool_entries && waves * k.pool_threshold > max_pool_entries) k.pool_threshold = (uint32_t)(max_pool_entries / waves);
         if (k.pool_threshold == 0) out->compact = false;

@@ -18,8 +18,8 @@ flops = json.loads((PROF / "flop_per_ray.json").read_text())
 CONFIGS = {
     "cornell": ("r02_cornell", "--scene cornell --width 1920 --height 1080 --spp 256 --lanes-per-pixel 4 --compact", 887.0),
     "glass": ("r02_glass", "--scene glass_spheres --width 1920 --height 1080 --spp 512 --bounces 32 --lanes-per-pixel 8 --compact", flops["glass"]["flop_per_ray"]),
-    "spheres4096": ("r02_spheres4096", "--scene random_spheres --count 4096 --width 1920 --height 1080 --spp 64 --lanes-per-pixel 1 --compact", flops["spheres4096"]["flop_per_ray"]),
-    "spheres": ("r02_spheres", "--scene spheres --width 1280 --height 720 --spp 512 --lanes-per-pixel 4 --compact", flops["spheres"]["flop_per_ray"]),
+    "spheres4096": ("r02_spheres4096", "--scene random_spheres --count 4096 --width 1920 --height 1080 --spp 64 --lanes-per-pixel 4 --compact", flops["spheres4096"]["flop_per_ray"]),
+    "spheres": ("r02_spheres", "--scene spheres --width 1280 --height 720 --spp 512 --lanes-per-pixel 8 --compact", flops["spheres"]["flop_per_ray"]),
 }
 for name, (tag, args, f) in CONFIGS.items():
     log = (OUT / tag / "stats.log").read_text()
