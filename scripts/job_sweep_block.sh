@@ -1,3 +1,4 @@
+# Runs on the GPU box: bench.py on all configurations at workgroup sizes 64 / 128 / 256 (RT_BLOCK_THREADS).
 set -e
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for bt in 64 128 256; do

@@ -1,3 +1,4 @@
+# Runs on the GPU box: one configuration (CFG, default glass) over lanes per pixel and hand-over bounds, compacted and single launch.
 set -e
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 run() { echo "== $*"; env "$@" CONFIG_LIST="${CFG:-glass}" STEPS=3 bash scripts/job_configs.sh sweep | tail -1; }
