@@ -36,6 +36,8 @@ CONFIGS = {
                     label="Cornell box 1920x1080"),
     "cornell1024": dict(scene=("cornell",), width=1920, height=1080, spp=1024, bounces=8, lanes=4,
                         label="Cornell box 1920x1080"),
+    "cornell4k": dict(scene=("cornell",), width=3840, height=2160, spp=4096, bounces=8, lanes=4,
+                      label="Cornell box 3840x2160"),
     "spheres": dict(scene=("spheres",), width=1280, height=720, spp=512, bounces=8, lanes=8,
                     label="spheres + plane (the reference's createScene) 1280x720"),
     "spheres4096": dict(scene=("random_spheres", 4096, 1), width=1920, height=1080, spp=64, bounces=8, lanes=4,
@@ -325,7 +327,8 @@ def main():
             workload = f"{label} {spp} spp on one GPU"
         compacted = not args.no_compact and spp // B_lanes >= 8       # the library's rule (rt_api.hip)
         line = {
-            "metric": "Mrays/s (whole node) Cornell box 1080p" if args.config.startswith("cornell") else f"Mrays/s (whole node) {args.config}",
+            "metric": ("Mrays/s (whole node) Cornell box 1080p" if (W, H) == (1920, 1080) else f"Mrays/s (whole node) Cornell box {W}x{H}")
+                      if args.config.startswith("cornell") else f"Mrays/s (whole node) {args.config}",
             "value": round(mrays, 1),
             "unit": "Mrays/s",
             "n_gpus": world_size,

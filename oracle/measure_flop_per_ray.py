@@ -70,6 +70,7 @@ def measure(name):
 if __name__ == "__main__":
     out = {name: measure(name) for name in CONFIGS}
     out["cornell1024"] = out["cornell"]
+    out["cornell4k"] = out["cornell"]      # the same scene and bounce cap at another image size and sample count
     path = ROOT / "profiles" / "flop_per_ray.json"
     path.write_text(json.dumps(out, indent=1) + "\n")
     for k, v in out.items():
