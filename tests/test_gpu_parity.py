@@ -370,14 +370,14 @@ def test_tail_compaction_over_random_parameters(ctx, cornell, spheres):
         ctx.upload_world(scenes[it % 4])
         lanes = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
-        kw = dict(lanes_per_pixel=lanes, max_bounces=int(rng.choice([1, 4, 8, 32])), intersect_mode=int(rng.integers(0, 2)),
+        kw = dict(lanes_per_pixel=lanes, max_bounces=int(rng.choice([1, 4, 8, 32])), intersect_mode=int(rng.integers(0, 3)),
                   batch_offset=int(rng.integers(0, 1000)))
         if rng.random() < 0.3 and h > 8:
             kw.update(band_rows=int(rng.choice([1, 4, 8])), band_count=int(rng.integers(2, 5)))
             kw["band_index"] = int(rng.integers(0, kw["band_count"]))
         if rng.random() < 0.3:
             kw["flags"] = B.FLAG_OUTPUT_SUM
-        p = B.default_params(w, h, lanes * int(rng.integers(52, 90)), **kw)
+        p = B.default_params(w, h, lanes * int(rng.integers(8, 90)), **kw)     # compaction is on from 8 samples per lane
         if B.local_row_count(p) == 0:
             continue
         plain = ctx.render(p)
