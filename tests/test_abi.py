@@ -82,3 +82,37 @@ def test_create_without_a_gpu_fails_loudly():
     with pytest.raises(B.RtError) as err:
         B.Context(0)
     assert err.value.status == 2
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/rt_hip.h is the boundary for any language with a C FFI: it compiles as C89-with-stdint and as C++,
+    and a C program linked against librt_hip.so can call the entry points that need no GPU."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "rt_hip.h"
+int main(void) {
+    rt_render_params p;
+    rt_default_params(&p, 1280, 720, 512);
+    if (p.struct_size != sizeof p || p.max_bounces != 8 || p.seed_constant != 262346u) return 1;
+    p.band_rows = 8; p.band_index = 1; p.band_count = 4;
+    if (rt_local_row_count(&p) != 184 || rt_global_row(&p, 8) != 40) return 2;   /* bands 1, 5, 9, ... of 90 */
+    if (rt_abi_version() != 1) return 3;
+    if (strlen(rt_status_string(RT_ERR_TOO_LARGE)) == 0) return 4;
+    if (rt_render(NULL, &p, NULL, NULL, NULL) == RT_OK) return 5;                /* no context: an error, not a crash */
+    printf("ok\n");
+    return 0;
+}
+''')
+    include, libdir = ROOT / "include", ROOT / "raytracer_amd"
+    exe = tmp_path / "use"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{include}", str(src), "-o", str(exe),
+                    f"-L{libdir}", "-lrt_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "ok"
+    cpp = tmp_path / "use.cpp"
+    cpp.write_text('#include "rt_hip.h"\nint main() { rt_render_params p; rt_default_params(&p, 4, 4, 1); return p.width == 4 ? 0 : 1; }\n')
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", f"-I{include}", str(cpp), "-o", str(tmp_path / "usecpp"),
+                    f"-L{libdir}", "-lrt_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(tmp_path / "usecpp")]).returncode == 0
