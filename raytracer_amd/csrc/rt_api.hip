@@ -11,9 +11,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -30,6 +32,7 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 struct rt_context {
     int device = -1;
     unsigned char* static_scratch = nullptr;   // this device's copy of `scratch`
+    mutable std::map<std::tuple<const void*, uint32_t, size_t>, uint32_t> stage2_residency;   // see stage2_waves_per_cu
     hipDeviceProp_t props{};
     std::string error;
 
@@ -110,7 +113,6 @@ struct Launch {
     uint32_t blocks, block_threads;
     int imode, rmode;
     bool compact = false;            // RT_FLAG_COMPACT_TAILS on per-pixel streams: stages 1 + 2 + combine
-    uint32_t stage2_blocks = 0;
 };
 
 // `max_pool_entries` (0 = no limit) caps the pool of handed-over streams: the hand-over threshold is lowered
@@ -217,10 +219,6 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         const uint64_t capacity = blocks * (out->block_threads / 64u) * k.pool_threshold;
         if (capacity > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "image too large for RT_FLAG_COMPACT_TAILS");
         k.pool_capacity = (uint32_t)capacity;
-        // Stage 2 runs persistent waves that fetch streams until the pool is empty: four waves per SIMD.
-        const uint64_t stage2_waves = (uint64_t)ctx->props.multiProcessorCount * env_or("RT_STAGE2_WAVES_PER_CU", 16, 1, 64);
-        const uint64_t stage2_blocks = (stage2_waves * 64u + out->block_threads - 1) / out->block_threads;
-        out->stage2_blocks = (uint32_t)(stage2_blocks < blocks ? stage2_blocks : blocks);
     }
 
     // Film constants (main.cpp:350-368), rounded operation by operation.
@@ -241,11 +239,37 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     return RT_OK;
 }
 
+// Persistent waves of stage 2 per CU: as many as the kernel variant keeps resident (it depends on the variant's
+// registers: 32 for rectangles only, 28 / 20 with few / many spheres), but no more than 24 - beyond that the
+// Cornell bench gets slower (sweep 8 / 16 / 24 / 32: 19.83 / 19.68 / 19.65 / 19.75 ms), below the residency the
+// sphere scenes do (4096 spheres at 16 / 20: 493 / 489 ms).  Queried once per (kernel, workgroup size, LDS size).
+uint32_t stage2_waves_per_cu(const rt_context* ctx, const void* kernel, uint32_t block_threads, size_t lds_bytes) {
+    static const uint32_t forced = env_or("RT_STAGE2_WAVES_PER_CU", 0, 0, 64);
+    if (forced) return forced;
+    const auto key = std::make_tuple(kernel, block_threads, lds_bytes);
+    auto found = ctx->stage2_residency.find(key);
+    if (found != ctx->stage2_residency.end()) return found->second;
+    int blocks_per_cu = 0;
+    uint32_t waves = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, (int)block_threads, lds_bytes) == hipSuccess && blocks_per_cu > 0)
+        waves = (uint32_t)blocks_per_cu * (block_threads / 64u);
+    waves = waves > 24u ? 24u : waves < 4u ? 4u : waves;
+    ctx->stage2_residency[key] = waves;
+    return waves;
+}
+
 template <int IMODE, int RMODE, int PRIMS, int STAGE>
-hipError_t launch_variant(const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels, float* d_radiance,
-                          unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
+hipError_t launch_variant(const rt_context* ctx, const Launch& L, size_t lds_bytes, const uint4* image, uint32_t* d_pixels,
+                          float* d_radiance, unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream, bool plan_only) {
     auto kernel = rt::render_kernel<IMODE, RMODE, PRIMS, STAGE>;
-    const uint32_t blocks = STAGE == 2 ? L.stage2_blocks : L.blocks;
+    uint32_t blocks = L.blocks;
+    if (STAGE == 2) {   // (also called with plan_only by rt_reserve, so that the query below never runs inside a captured launch)
+        const uint64_t waves = (uint64_t)ctx->props.multiProcessorCount *
+                               stage2_waves_per_cu(ctx, reinterpret_cast<const void*>(kernel), L.block_threads, lds_bytes);
+        const uint64_t wanted = (waves * 64u + L.block_threads - 1) / L.block_threads;
+        blocks = (uint32_t)(wanted < L.blocks ? wanted : L.blocks);
+    }
+    if (plan_only) return hipSuccess;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(L.block_threads), lds_bytes, stream, L.kp, image, d_pixels, d_radiance,
                        d_rays, ws);
     return hipGetLastError();
@@ -275,7 +299,7 @@ hipError_t allow_dynamic_lds(size_t bytes) {
 }
 
 hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d_pixels, float* d_radiance,
-                  unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream) {
+                  unsigned long long* d_rays, const rt::Workspace& ws, hipStream_t stream, bool plan_only = false) {
     const uint4* image = ctx->d_image[L.imode];
     // the staged scene image, plus one sphere staging slice per wave when the world has spheres
     const size_t lds = (size_t)ctx->lds_words * 4 + (ctx->sphere_count ? (size_t)(L.block_threads / 64u) * rt::SPHERE_SLICE_BYTES : 0u);
@@ -285,7 +309,7 @@ hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d
                       : !ctx->sphere_count ? rt::PRIMS_RECTS : ctx->sphere_count <= 64u ? rt::PRIMS_FEW_SPHERES : rt::PRIMS_SPHERES;
 #define RT_DISPATCH(IM, RM, PR, ST)                                                  \
     if (kernel_imode == IM && L.rmode == RM && prims == PR && stage == ST)           \
-        return launch_variant<IM, RM, PR, ST>(L, lds, image, d_pixels, d_radiance, d_rays, ws, stream);
+        return launch_variant<IM, RM, PR, ST>(ctx, L, lds, image, d_pixels, d_radiance, d_rays, ws, stream, plan_only);
     RT_FOR_EACH_KERNEL(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
@@ -721,7 +745,9 @@ static rt_status reserve_impl(rt_context* ctx, const rt_render_params* params) {
     rt_status st = validate_and_plan(ctx, params, &L);
     if (st != RT_OK) return st;
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return L.compact ? ensure_workspace(ctx, L) : RT_OK;
+    if (!L.compact) return RT_OK;
+    RT_HIP_CHECK(ctx, launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true));   // sizes stage 2 now
+    return ensure_workspace(ctx, L);
 }
 
 static rt_status load_accumulator_impl(rt_context* ctx, const rt_render_params* params, const float* radiance_sum) {
