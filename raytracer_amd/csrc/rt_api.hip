@@ -11,11 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
-#include <tuple>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -32,7 +30,10 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 struct rt_context {
     int device = -1;
     unsigned char* static_scratch = nullptr;   // this device's copy of `scratch`
-    mutable std::map<std::tuple<const void*, uint32_t, size_t>, uint32_t> stage2_residency;   // see stage2_waves_per_cu
+    // stage2_waves_per_cu's answers (no heap: the no-allocation entry point may be the first to ask)
+    struct Residency { const void* kernel; uint32_t block_threads; size_t lds_bytes; uint32_t waves; };
+    mutable Residency stage2_residency[32];
+    mutable uint32_t stage2_residency_count = 0;
     hipDeviceProp_t props{};
     std::string error;
 
@@ -115,6 +116,19 @@ struct Launch {
     bool compact = false;            // RT_FLAG_COMPACT_TAILS on per-pixel streams: stages 1 + 2 + combine
 };
 
+// A CU has 160 KB of LDS and room for 2048 threads: the workgroup size is picked so that the LDS copies of
+// the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
+uint32_t workgroup_threads(const rt_context* ctx) {
+    const size_t image_bytes = (size_t)ctx->lds_words * 4;
+    uint32_t threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
+    // Worlds with spheres: one wave per workgroup.  Their waves last long and unevenly (every ray tests every
+    // sphere), and a workgroup keeps its waves' slots until its last wave ends (measured with 256 threads on the
+    // 4096-sphere scene: 2.8 of 4 possible waves resident on average; one wave per workgroup: +8 %).
+    if (ctx->sphere_count && image_bytes <= 8u * 1024u) threads = 64u;
+    if (const uint32_t forced = env_or("RT_BLOCK_THREADS", 0, 0, 1024)) threads = forced & ~63u ? forced & ~63u : 64u;   // experiments
+    return threads;
+}
+
 // `max_pool_entries` (0 = no limit) caps the pool of handed-over streams: the hand-over threshold is lowered
 // until waves * threshold entries fit, and with no room at all the render is planned as a single launch.
 rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out, uint64_t max_pool_entries = 0) {
@@ -192,15 +206,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         out->compact = (p->flags & RT_FLAG_COMPACT_TAILS) != 0 && k.samples_per_lane >= MIN_SAMPLES_PER_LANE_TO_COMPACT &&
                        k.samples_per_lane >= 4 * (pool_max_samples(k.samples_per_lane) + 1);
     }
-    // A CU has 160 KB of LDS and room for 2048 threads: pick the workgroup size so that the LDS
-    // copies of the scene image leave the CU full (small image: 256 threads; > 40 KB: 512; > 80 KB: 1024).
-    const size_t image_bytes = (size_t)k.lds_words * 4;
-    out->block_threads = image_bytes > 80u * 1024u ? 1024u : image_bytes > 40u * 1024u ? 512u : 256u;
-    // Worlds with spheres: one wave per workgroup.  Their waves last long and unevenly (every ray tests every
-    // sphere), and a workgroup keeps its waves' slots until its last wave ends (measured with 256 threads on the
-    // 4096-sphere scene: 2.8 of 4 possible waves resident on average; one wave per workgroup: +8 %).
-    if (ctx->sphere_count && image_bytes <= 8u * 1024u) out->block_threads = 64u;
-    if (const uint32_t forced = env_or("RT_BLOCK_THREADS", 0, 0, 1024)) out->block_threads = forced & ~63u ? forced & ~63u : 64u;   // experiments
+    out->block_threads = workgroup_threads(ctx);
     uint64_t blocks = (lanes + out->block_threads - 1) / out->block_threads;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "launch grid out of range");
     // The kernels index lanes and streams (pixel * lanes_per_pixel + batch) with 32-bit integers.
@@ -246,15 +252,17 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
 uint32_t stage2_waves_per_cu(const rt_context* ctx, const void* kernel, uint32_t block_threads, size_t lds_bytes) {
     static const uint32_t forced = env_or("RT_STAGE2_WAVES_PER_CU", 0, 0, 64);
     if (forced) return forced;
-    const auto key = std::make_tuple(kernel, block_threads, lds_bytes);
-    auto found = ctx->stage2_residency.find(key);
-    if (found != ctx->stage2_residency.end()) return found->second;
+    for (uint32_t i = 0; i < ctx->stage2_residency_count; ++i) {
+        const rt_context::Residency& r = ctx->stage2_residency[i];
+        if (r.kernel == kernel && r.block_threads == block_threads && r.lds_bytes == lds_bytes) return r.waves;
+    }
     int blocks_per_cu = 0;
     uint32_t waves = 16;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, (int)block_threads, lds_bytes) == hipSuccess && blocks_per_cu > 0)
         waves = (uint32_t)blocks_per_cu * (block_threads / 64u);
     waves = waves > 24u ? 24u : waves < 4u ? 4u : waves;
-    ctx->stage2_residency[key] = waves;
+    if (ctx->stage2_residency_count == 32) ctx->stage2_residency_count = 0;   // a new world every time: start over
+    ctx->stage2_residency[ctx->stage2_residency_count++] = {kernel, block_threads, lds_bytes, waves};
     return waves;
 }
 
@@ -725,6 +733,13 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     ctx->mixed = w->sphere_count && w->rectangle_count;
     ctx->has_world = true;
     ctx->accumulator_valid = false;
+    // Size stage 2 for this world's kernel variants now (an occupancy query each), so that no later launch -
+    // a captured one, or the entry point that must not allocate - is the first to ask.
+    for (int imode : {RT_INTERSECT_WIDE8, RT_INTERSECT_SCALAR}) {
+        Launch L;
+        L.imode = imode; L.rmode = RT_RNG_PIXEL; L.blocks = 1; L.block_threads = workgroup_threads(ctx);
+        RT_HIP_CHECK(ctx, launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true));
+    }
     return RT_OK;
 }
 
