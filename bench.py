@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--lanes-per-pixel", type=int, default=0)
     ap.add_argument("--no-compact", action="store_true", help="single-launch render (no tail compaction)")
+    ap.add_argument("--no-cull", action="store_true", help="switch the per-wave primary-ray cull off (A/B measurements)")
     ap.add_argument("--shard", choices=("samples", "rows"), default="samples")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all render on GPU 0 and exchange through gloo + host copies: exercises the multi-rank path "
@@ -183,7 +184,7 @@ def main():
 
     rows_mode = distributed and args.shard == "rows"
     base = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes, max_bounces=cfg["bounces"],
-                            flags=0 if args.no_compact else B.FLAG_COMPACT_TAILS)
+                            flags=(0 if args.no_compact else B.FLAG_COMPACT_TAILS) | (B.FLAG_NO_PRIMARY_CULL if args.no_cull else 0))
     total = args.steps + args.warmup
     rays = torch.zeros(total, dtype=torch.int64, device=device)
     radiance = gathered = sharded = None

@@ -127,7 +127,11 @@ enum {  /* rt_render_params.flags */
      * lives in the context: it is started by a render of the same rows with RT_FLAG_OUTPUT_SUM (or set with
      * rt_load_accumulator), every RT_FLAG_ACCUMULATE render adds to it, and `radiance` (may be NULL) receives
      * a copy.  Resolve the image at the end with rt_resolve / rt_resolve_device. */
-    RT_FLAG_ACCUMULATE = 8u
+    RT_FLAG_ACCUMULATE = 8u,
+    /* RT_RNG_PIXEL renders skip, in iterations whose rays are all primary rays, the rectangles that no primary
+     * ray of the wave's pixel tile can reach (decided once per wave, conservatively: same pixels, same ray
+     * count).  This flag switches the skip off, for A/B measurements and tests. */
+    RT_FLAG_NO_PRIMARY_CULL = 16u
 };
 
 typedef struct rt_render_params {

@@ -242,6 +242,32 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     k.half_h = film_h * 0.5f;
     k.pixel_w = 0.5f / (float)(int32_t)p->width;
     k.pixel_h = 0.5f / (float)(int32_t)p->height;
+
+    // Primary-ray cull (rt_kernels.hpp, primary_pair_mask): a wave decides once which rectangles the primary rays
+    // of its pixel tile can reach, from the tile's patch of the film widened by this margin on every side, in
+    // film-plane units (one pixel is 1 / height wide in them).  The margin is one pixel plus a bound on how far
+    // the kernel's rounded ray set-up (film position, direction, normalisation: about a dozen operations on
+    // values of the camera position's magnitude) can move a ray on the film plane.  That bound reads the ray's
+    // error through the camera axes, so the cull is used only with axes that are orthonormal to 1e-3.
+    k.cull_margin = 0.0f;
+    if (p->rng_mode == RT_RNG_PIXEL && !(p->flags & RT_FLAG_NO_PRIMARY_CULL)) {
+        const float* axes[3] = {c.x_axis, c.y_axis, c.z_axis};
+        bool orthonormal = true;
+        double reach = 4.0;
+        for (int i = 0; i < 3; ++i) {
+            reach = std::fmax(reach, 4.0 + std::fabs((double)c.position[i]));
+            for (int j = i; j < 3; ++j) {
+                const double g = (double)axes[i][0] * axes[j][0] + (double)axes[i][1] * axes[j][1] + (double)axes[i][2] * axes[j][2];
+                orthonormal = orthonormal && std::fabs(g - (i == j ? 1.0 : 0.0)) <= 1.0e-3;
+            }
+        }
+        if (orthonormal) {
+            k.cull_margin = (float)(1.0 / (double)p->height + 0x1.0p-20 * reach);
+            // no primary direction D0 + a camX + b camY is longer than this (|a| <= half_w (1 + pixel_w) + margin, same for b)
+            k.cull_reach = (float)(1.002 * (1.0 + ((double)k.half_w * (1.0 + k.pixel_w) + k.cull_margin) +
+                                            ((double)k.half_h * (1.0 + k.pixel_h) + k.cull_margin)));
+        }
+    }
     return RT_OK;
 }
 

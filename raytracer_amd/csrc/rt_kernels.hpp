@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 
 #include "rt_layout.hpp"
 
@@ -42,6 +43,8 @@ struct KernelParams {
     uint32_t sphere_count, sphere_offset, sphere_tag_offset;   // sphere sections of the global image (words)
     float cam_pos[3], cam_x[3], cam_y[3], film_center[3];
     float half_w, half_h, pixel_w, pixel_h;
+    float cull_margin;      // PIXEL: > 0 enables the per-wave primary-ray cull; film-plane widening of a tile's footprint (see primary_pair_mask)
+    float cull_reach;       // upper bound on the length of an un-normalised primary direction (film at distance 1)
 };
 
 // Device workspace of the tail compaction: per-stream sums, the pool of unfinished streams and its fill count.
@@ -51,16 +54,18 @@ struct Workspace {
     uint4* pool;              // POOL_VEC4 x uint4 per deposited stream
     uint32_t* pool_count;     // streams deposited by STAGE 1
 };
+// A pool entry: sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
 constexpr uint32_t POOL_VEC4 = 5;
 // Per-wave LDS slice of worlds with spheres: 64 staged sphere records (16 B each), then their 64 tags.
-constexpr uint32_t SPHERE_SLICE_BYTES = 1280u;   // sid state samples_left bounce | sum.xyz ro.x | ro.yz dir.xy | dir.z att.xyz | result.xyz 0
+constexpr uint32_t SPHERE_SLICE_BYTES = 1280u;
 
 // Diagnostic build only (-DRT_STAMPS, never the shipped library): every wave adds up the shader-clock
 // cycles it spends in each region of the render loop, and a few event counts, and adds them to a global
 // table when it ends.  The stamps cost about a tenth of the run time, so the table is read as shares.
 enum : int { ST_START = 0, ST_CONTROL, ST_PLANES, ST_SPHERE_TERMS, ST_SPHERE_ROOTS, ST_RECTS, ST_RESOLVE, ST_SHADE, ST_EPILOGUE,
              CT_ITERATIONS, CT_LANES_TRACING, CT_ROOTS_BODIES, CT_ROOTS_LANES, CT_START_LANES, CT_HIT_LANES, CT_DIELECTRIC_BODIES,
-             CT_DIELECTRIC_LANES, CT_RECT_PAIRS, CT_RECT_PAIRS_BEHIND, CT_RECTS_OUT_OF_RANGE, CT_RECT_RANGE_LANES, ST_COUNT };
+             CT_DIELECTRIC_LANES, CT_RECT_PAIRS, CT_RECT_PAIRS_BEHIND, CT_RECTS_OUT_OF_RANGE, CT_RECT_RANGE_LANES,
+             CT_RECT_PAIRS_SKIPPED, CT_RECT_PAIR_RAYS, ST_COUNT };
 constexpr int MAX_STAMP_WAVES = 16;
 #ifdef RT_STAMPS
 __device__ unsigned long long rt_stamp_table[ST_COUNT];
@@ -329,13 +334,62 @@ __device__ __forceinline__ void update_closest_sphere(float t, float min_hit, ui
     }
 }
 
+// Primary-ray cull.  The pixels of a wave form a fixed tile of the image, so every primary ray the wave will
+// ever trace leaves the camera position through one small patch of the film: the tile's pixel centres, the
+// jitter of a quarter pixel around them (main.cpp:381-382), and a widening `cull_margin` (one pixel plus a bound
+// on the rounding of the kernel's own ray set-up) chosen by the host.  In un-normalised direction space the
+// patch is the parallelogram D(a, b) = D0 + a * camX + b * camY over a box [a_lo, a_hi] x [b_lo, b_hi].  For
+// every rectangle the host has reduced the question "can a ray of direction D(a, b) from the camera pass the
+// rectangle test of the loop below (main.cpp:96-129)?" to the signs of five functions that are LINEAR in
+// (a, b) (cull table of the scene image, rt_layout.hpp): a linear function takes its extremes over a box at
+// the corners picked by the signs of its two slopes, so each costs two multiply-adds here.  Lane j decides for
+// rectangle pair j; the ballot of the answers is the set of pairs that iterations in which all rays are
+// primary rays have to visit.  Anything not provably missed is kept, and culled pairs can never replace the
+// closest hit, so skipping them changes neither the winner nor any later arithmetic.
+__device__ __forceinline__ unsigned long long primary_pair_mask(const double* __restrict__ cull_table, const SceneView& sv,
+                                                                const KernelParams& p, uint32_t x0, uint32_t x1, uint32_t row0,
+                                                                uint32_t row1) {
+    const uint32_t lane = threadIdx.x & 63u, n_pairs = sv.n_rects / 2u;
+    // The box: film coordinates as main.cpp:375-388 forms them (float; their rounding is four orders of magnitude
+    // below the widening), jitter, margin.
+    const float fx0 = ((float)(int32_t)x0 / (float)(int32_t)p.width) * 2.0f - 1.0f, fx1 = ((float)(int32_t)x1 / (float)(int32_t)p.width) * 2.0f - 1.0f;
+    const float fy0 = ((float)(int32_t)row0 / (float)(int32_t)p.height) * -2.0f + 1.0f, fy1 = ((float)(int32_t)row1 / (float)(int32_t)p.height) * -2.0f + 1.0f;   // fy1 <= fy0
+    const double a_lo = (double)((fx0 - p.pixel_w) * p.half_w - p.cull_margin), a_hi = (double)((fx1 + p.pixel_w) * p.half_w + p.cull_margin);
+    const double b_lo = (double)((fy1 - p.pixel_h) * p.half_h - p.cull_margin), b_hi = (double)((fy0 + p.pixel_h) * p.half_h + p.cull_margin);
+    // extremes of alpha + beta a + gamma b over the box
+    auto lowest = [&](const double* f) { return f[0] + (f[1] > 0.0 ? f[1] * a_lo : f[1] * a_hi) + (f[2] > 0.0 ? f[2] * b_lo : f[2] * b_hi); };
+    auto highest = [&](const double* f) { return f[0] + (f[1] > 0.0 ? f[1] * a_hi : f[1] * a_lo) + (f[2] > 0.0 ? f[2] * b_hi : f[2] * b_lo); };
+    bool keep = false;
+#pragma unroll 1
+    for (uint32_t which = 0; which < (lane < n_pairs ? 2u : 0u); ++which) {
+        const double* rec = cull_table + (size_t)CULL_DOUBLES * (2u * lane + which);
+        const double grazing = rec[CULL_GRAZING];
+        if (grazing < 0.0) continue;                        // a rectangle that nothing can hit (zero padding)
+        // d'z = r2 . D keeps one sign over the patch and no ray is within 1e-3 (as a cosine) of parallel to the plane?
+        const double limit = grazing * (double)p.cull_reach;
+        const bool all_pos = lowest(rec + CULL_W) >= limit, all_neg = highest(rec + CULL_W) <= -limit;
+        if (!(all_pos || all_neg)) { keep = true; continue; }                      // not decided here
+        const double oz = rec[CULL_OZ];
+        if (oz == 0.0 || (oz > 0.0) == all_pos) continue;                        // t = -o'z / d'z <= 0 for every ray
+        // In front: all rays pass the plane beyond one edge of the square, margin included?
+        const bool right = all_pos ? lowest(rec + CULL_RIGHT) > 0.0 : highest(rec + CULL_RIGHT) < 0.0;
+        const bool left = all_pos ? highest(rec + CULL_LEFT) < 0.0 : lowest(rec + CULL_LEFT) > 0.0;
+        const bool above = all_pos ? lowest(rec + CULL_ABOVE) > 0.0 : highest(rec + CULL_ABOVE) < 0.0;
+        const bool below = all_pos ? highest(rec + CULL_BELOW) < 0.0 : lowest(rec + CULL_BELOW) > 0.0;
+        if (!(right || left || above || below)) keep = true;
+    }
+    return __ballot(keep);
+}
+
 // `camera_origin` (wave-uniform): every lane's ray starts at the camera position, so the rectangles'
 // origin transforms are read from the scene image, where the host stored them, instead of computed.
+// `primary_pairs` (wave-uniform): the rectangle pairs such an iteration has to visit (bit i: pair i; pairs
+// from 64 on are always visited).
 // Variants with spheres must be called by ALL 64 lanes of the wave (the lanes stage the sphere records
 // together); `active` says whether this lane has a ray, and only active lanes test anything.
 template <int IMODE, int PRIMS>
 __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3 d, float min_hit, float plane_tol,
-                                                   bool camera_origin, bool active, Stamps& st) {
+                                                   bool camera_origin, unsigned long long primary_pairs, bool active, Stamps& st) {
     constexpr bool MIXED = PRIMS == PRIMS_BOTH && IMODE == RT_INTERSECT_WIDE8;
     float best_t = 3.402823466e+38f;  // F32Max
     uint32_t best_id = 0;
@@ -501,11 +555,15 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     const F2 ox2 = splat(o.x), oy2 = splat(o.y), oz2 = splat(o.z);
     const F2 dx2 = splat(d.x), dy2 = splat(d.y), dz2 = splat(d.z);
     const uint32_t rect_base = 1 + sv.n_planes + sv.n_spheres;
-    for (uint32_t pair = 0; pair < ((PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u); ++pair) {
+    const uint32_t n_pairs = (PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u;
+    // One pair.  CAMERA is a compile-time copy of camera_origin: the loop exists twice, so that neither copy
+    // branches on it.
+    auto test_pair = [&](uint32_t pair, auto camera_tag) {
+        constexpr bool CAMERA = decltype(camera_tag)::value;
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
         const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3], z01 = rec[4], z23 = rec[5];
         F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
-        if (camera_origin) {
+        if (CAMERA) {
             const float4 c01 = rec[8], c2 = rec[9];
             a_lo = f2(c01.x, c01.y); b_lo = f2(c01.z, c01.w); z_lo = f2(c2.x, c2.y);
         } else if (IMODE == RT_INTERSECT_WIDE8) {
@@ -562,6 +620,20 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                 if (MIXED) best_lane = 0;
             }
         }
+    };
+    if (camera_origin) {
+        // All rays are primary rays: only the pairs one of them can hit (primary_pair_mask), in increasing order.
+        unsigned long long todo = n_pairs >= 64u ? primary_pairs : primary_pairs & ((1ull << n_pairs) - 1ull);
+        st.count(CT_RECT_PAIRS_SKIPPED, (n_pairs < 64u ? n_pairs : 64u) - (unsigned long long)__builtin_popcountll(todo));
+        st.count(CT_RECT_PAIR_RAYS, RT_LANES(active) * ((unsigned long long)__builtin_popcountll(todo) + (n_pairs > 64u ? n_pairs - 64u : 0u)));
+        while (todo) {
+            test_pair((uint32_t)__builtin_ctzll(todo), std::true_type());
+            todo &= todo - 1ull;
+        }
+        for (uint32_t pair = 64; pair < n_pairs; ++pair) test_pair(pair, std::true_type());
+    } else {
+        st.count(CT_RECT_PAIR_RAYS, RT_LANES(active) * n_pairs);
+        for (uint32_t pair = 0; pair < n_pairs; ++pair) test_pair(pair, std::false_type());
     }
     st.mark(ST_RECTS);
     Closest c;
@@ -708,6 +780,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     uint32_t sid = 0;                     // PIXEL: index of the lane's stream, pixel * lanes_per_pixel + batch
     bool has_pixel = false;               // the lane still owns an unfinished pixel
     bool pixel_valid = false;             // PIXEL: lane maps to a pixel inside the image
+    unsigned long long primary_pairs = ~0ull;   // rectangle pairs that iterations of primary rays only have to visit
 
     if (RMODE == RT_RNG_ROW_SERIAL) {
         if (gid < p.order_count) {
@@ -736,6 +809,12 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             has_pixel = true;
             samples_left = p.samples_per_lane;
             sid = (ly * p.width + x) * p.lanes_per_pixel + b;
+        }
+        // The wave's tile is fixed for its lifetime: decide once which rectangle pairs its primary rays can reach.
+        if ((PRIMS & PRIMS_RECTS) && p.cull_margin > 0.0f && column_rank < p.tiles_x) {
+            const uint32_t x0 = tile_x * p.tile_w, ly0 = tile_y * p.tile_h;
+            primary_pairs = primary_pair_mask(reinterpret_cast<const double*>(reinterpret_cast<const uint32_t*>(scene_image) + sv.u[H_OFF_CULL]), sv, p, x0, min(x0 + p.tile_w, p.width) - 1u, global_row(p, ly0),
+                                              global_row(p, min(ly0 + p.tile_h, p.local_rows) - 1u));
         }
     }
     // STAGE 2: persistent waves; every lane fetches deposited streams from the pool until it is empty.
@@ -849,13 +928,13 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         if (PRIMS & PRIMS_SPHERES) {
             if (in_path) rd = normalize(next_dir);
             st.mark(ST_CONTROL);
-            c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, in_path, st);
+            c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, primary_pairs, in_path, st);
         }
         if (in_path) {
             if (!(PRIMS & PRIMS_SPHERES)) {
                 rd = normalize(next_dir);
                 st.mark(ST_CONTROL);
-                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, true, st);
+                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, primary_pairs, true, st);
             }
             ++pixel_rays;
             ++bounce;

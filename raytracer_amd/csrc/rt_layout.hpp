@@ -21,6 +21,8 @@
 //   -------- end of the LDS part --------
 //   spheres   4 words  cx cy cz r*r                      (16-byte aligned)
 //   sph.tag   1 word   material | wide_lane << 24
+//   cull     36 words  per rectangle SLOT (pair k: slots 2k, 2k+1): 18 doubles that let a wave decide whether any
+//                      primary ray through its pixel tile can hit the rectangle (see cull_record below)
 //
 // RT_INTERSECT_WIDE8 order: the reference tests primitives 8 at a time, lane j of
 // group g being primitive 8g+j, keeps a running closest hit PER LANE and finally
@@ -42,7 +44,7 @@ namespace rt {
 
 enum : uint32_t {
     H_NPLANES = 0, H_NSPHERES, H_NRECTS, H_NMATS,
-    H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS, H_LDS_WORDS,
+    H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS, H_LDS_WORDS, H_OFF_CULL,
     H_WORDS = 16
 };
 
@@ -52,6 +54,66 @@ constexpr uint32_t TAG_LANE_SHIFT = 24;   // tag = material | lane << 24
 constexpr uint32_t TAG_MATERIAL_MASK = 0x00FFFFFFu;
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// Cull record of one rectangle (doubles).  A primary ray has the un-normalised direction
+// D(a, b) = D0 + a * camX + b * camY (D0 = film centre - camera position; a, b film-plane coordinates) and, in
+// the rectangle's frame, the origin o' (the floats stored for camera rays) and the direction
+// (u, v, w) = (r0.D, r1.D, r2.D), r0..r2 being the first three columns of the inverse transform's rows.  Each
+// triple below is (alpha, beta, gamma) of a function alpha + beta a + gamma b:
+//   W      w itself.  The rectangle is decided only where w keeps one sign over the tile's patch and
+//          |w| >= GRAZING * reach (reach >= |D|, so no ray is within 1e-3, as a cosine, of parallel to the plane):
+//          then the kernel's rounded d'z (error <= 4 ulp of |r2||d|) has that sign and is within 2e-4 of r2.d,
+//          relatively.  o'z == 0 or o'z of w's sign: t = -o'z / d'z <= 0 fails `t > min_hit`, no hit.
+//   RIGHT  (o'x - mx) w - u o'z, LEFT (o'x + mx) w - u o'z, ABOVE / BELOW the same with o'y, my, v.  Otherwise the
+//          exact hit point (o'x - u o'z / w, o'y - v o'z / w) is a projective image of the patch with a
+//          denominator of one sign, hence inside the convex hull of the patch corners' images, and
+//          sign(w) * RIGHT > 0 at the corners says they all have x > mx = 1 + M, with
+//          M = 1e-3 (1 + |o'x| + |r0|/|r2| |o'z|); the kernel's rounded hit point is within M / 4 of the exact one
+//          (relative error 2e-4 of t, 4 ulp of |r0||d| on d'x, times |t| <= |o'z| / (1e-3 |r2|)), so it fails
+//          |x| <= 1.  LEFT: all x < -mx; ABOVE / BELOW: the same for y.
+//   GRAZING  1e-3 |r2|; negative: nothing can hit the rectangle (zero padding, or a zero third row: t is NaN or
+//          infinite); +infinity: never decided (magnitudes outside [2^-40, 2^40], where the loop's shortened
+//          division is not in its exact range).
+//   OZ     o'z.
+enum : uint32_t { CULL_W = 0, CULL_RIGHT = 3, CULL_LEFT = 6, CULL_ABOVE = 9, CULL_BELOW = 12, CULL_GRAZING = 15, CULL_OZ = 16, CULL_DOUBLES = 18 };
+
+// m: the rectangle's inverse transform; o: the stored camera-origin transform (o'x, o'y, o'z).
+inline void cull_record(const float (*m)[4], const float o[3], const rt_camera& cam, double* rec) {
+    const double ox = o[0], oy = o[1], oz = o[2];
+    double r[3][3], n[3];
+    for (int row = 0; row < 3; ++row) {
+        for (int col = 0; col < 3; ++col) r[row][col] = (double)m[row][col];
+        n[row] = r[row][0] * r[row][0] + r[row][1] * r[row][1] + r[row][2] * r[row][2];
+    }
+    for (uint32_t i = 0; i < CULL_DOUBLES; ++i) rec[i] = 0.0;
+    rec[CULL_OZ] = oz;
+    if (n[2] == 0.0) { rec[CULL_GRAZING] = -1.0; return; }
+    const double big = 0x1.0p40, tiny = 0x1.0p-40;
+    const bool in_range = n[0] <= big * big && n[1] <= big * big && n[2] <= big * big && n[2] >= 0x1.0p-60 && std::fabs(ox) <= big &&
+                          std::fabs(oy) <= big && std::fabs(oz) <= big && (oz == 0.0 || std::fabs(oz) >= tiny);
+    if (!in_range) { rec[CULL_GRAZING] = INFINITY; return; }
+    rec[CULL_GRAZING] = 1.0e-3 * std::sqrt(n[2]);
+    const double mx = 1.0 + 1.0e-3 * (1.0 + std::fabs(ox) + std::sqrt(n[0] / n[2]) * std::fabs(oz));
+    const double my = 1.0 + 1.0e-3 * (1.0 + std::fabs(oy) + std::sqrt(n[1] / n[2]) * std::fabs(oz));
+    // D0 = film centre - camera position, the film centre rounded as the render does it (main.cpp:358-359)
+    double d0[3];
+    for (int i = 0; i < 3; ++i) {
+        const float film_center = cam.position[i] - cam.z_axis[i];
+        d0[i] = (double)film_center - (double)cam.position[i];
+    }
+    auto put = [&](uint32_t at, double w_scale, const double* other, double other_scale) {   // c = w_scale r2 + other_scale other
+        double c[3];
+        for (int i = 0; i < 3; ++i) c[i] = w_scale * r[2][i] + (other ? other_scale * other[i] : 0.0);
+        rec[at + 0] = c[0] * d0[0] + c[1] * d0[1] + c[2] * d0[2];
+        rec[at + 1] = c[0] * cam.x_axis[0] + c[1] * cam.x_axis[1] + c[2] * cam.x_axis[2];
+        rec[at + 2] = c[0] * cam.y_axis[0] + c[1] * cam.y_axis[1] + c[2] * cam.y_axis[2];
+    };
+    put(CULL_W, 1.0, nullptr, 0.0);
+    put(CULL_RIGHT, ox - mx, r[0], -oz);
+    put(CULL_LEFT, ox + mx, r[0], -oz);
+    put(CULL_ABOVE, oy - my, r[1], -oz);
+    put(CULL_BELOW, oy + my, r[1], -oz);
+}
 
 // Indices 0..n-1 sorted by (i % lanes, i / lanes).
 inline std::vector<uint32_t> wide_order(uint32_t n, uint32_t lanes) {
@@ -74,13 +136,20 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, uint32_t wide_l
     uint32_t lds_words = round4(off_mats + MAT_WORDS * w.material_count);
     uint32_t off_spheres = lds_words;
     uint32_t off_tags = off_spheres + SPHERE_WORDS * w.sphere_count;
-    uint32_t total = round4(off_tags + w.sphere_count);
+    uint32_t off_cull = round4(off_tags + w.sphere_count);          // doubles: 16-byte aligned
+    uint32_t total = off_cull + 2u * CULL_DOUBLES * rect_slots;
 
     std::vector<uint32_t> img(total, 0u);
     img[H_NPLANES] = w.plane_count; img[H_NSPHERES] = w.sphere_count;
     img[H_NRECTS] = rect_slots; img[H_NMATS] = w.material_count;
     img[H_OFF_PLANES] = off_planes; img[H_OFF_SPHERES] = off_spheres; img[H_OFF_SPHERE_TAGS] = off_tags;
     img[H_OFF_RECTS] = off_rects; img[H_OFF_MATS] = off_mats; img[H_TOTAL_WORDS] = total; img[H_LDS_WORDS] = lds_words;
+    img[H_OFF_CULL] = off_cull;
+    for (uint32_t k = w.rectangle_count; k < rect_slots; ++k) {    // the padding slot: never hit
+        double rec[CULL_DOUBLES] = {0.0};
+        rec[CULL_GRAZING] = -1.0;
+        std::memcpy(&img[off_cull + 2u * CULL_DOUBLES * k], rec, sizeof rec);
+    }
 
     for (uint32_t i = 0; i < w.plane_count; ++i) {
         const rt_plane& p = w.planes[i];
@@ -123,6 +192,9 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, uint32_t wide_l
             q[32 + 2 * which] = f2u(rows[0]);
             q[33 + 2 * which] = f2u(rows[1]);
             q[36 + which] = f2u(rows[2]);
+            double rec[CULL_DOUBLES];
+            cull_record(m, rows, *w.camera, rec);
+            std::memcpy(&img[off_cull + 2u * CULL_DOUBLES * k], rec, sizeof rec);
         }
         uint32_t* tail = q + 24 + 4 * which;
         tail[0] = f2u(r.normal[0]); tail[1] = f2u(r.normal[1]); tail[2] = f2u(r.normal[2]);

@@ -17,7 +17,11 @@ from raytracer_amd.host_scene import build_scene        # noqa: E402
 
 NAMES = ["start", "control+normalize", "planes", "sphere terms", "sphere roots", "rects", "resolve hit", "shade", "epilogue",
          "iterations", "lanes tracing", "roots bodies", "roots lanes", "start lanes", "hit lanes", "dielectric bodies", "dielectric lanes",
-         "rect pairs", "rect pairs behind", "rects out of range", "rect range lanes"]
+         "rect pairs", "rect pairs behind", "rects out of range", "rect range lanes", "rect pairs skipped", "rect pair rays"]
+
+
+def cfg_pairs(cfg):
+    return (len(build_scene(*cfg["scene"]).rectangles) + 1) // 2
 
 
 def main():
@@ -25,13 +29,14 @@ def main():
     lib.rt_debug_read_stamps.restype = C.c_int
     lib.rt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
     table = (C.c_ulonglong * len(NAMES))()
-    for name in sys.argv[1:] or ["cornell"]:
+    no_cull = "--no-cull" in sys.argv
+    for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["cornell"]:
         cfg = bench.CONFIGS[name]
         spp = max(cfg["lanes"] * 64, cfg["spp"] // 4)
         with B.Context(0) as ctx:
             ctx.upload_world(build_scene(*cfg["scene"]))
             p = B.default_params(cfg["width"], cfg["height"], spp, lanes_per_pixel=cfg["lanes"], max_bounces=cfg["bounces"],
-                                 flags=B.FLAG_COMPACT_TAILS)
+                                 flags=B.FLAG_COMPACT_TAILS | (B.FLAG_NO_PRIMARY_CULL if no_cull else 0))
             lib.rt_debug_read_stamps(None, 1)
             _, _, rays = ctx.render(p, want_radiance=False)
             lib.rt_debug_read_stamps(table, 1)
@@ -50,6 +55,8 @@ def main():
                   f"{100 * v['rect pairs behind'] / v['rect pairs']:.2f} %; rectangles that no lane's t can improve on "
                   f"(min_hit < t < closest fails on all lanes): {100 * v['rects out of range'] / (2 * v['rect pairs']):.2f} %, "
                   f"{v['rect range lanes'] / (2 * v['rect pairs']):.1f} lanes pass it on average")
+            print(f"   primary-ray cull: {v['rect pairs skipped'] / it:.3f} pairs skipped per iteration; "
+                  f"rectangle pairs tested per ray: {v['rect pair rays'] / v['lanes tracing']:.3f} of {cfg_pairs(cfg)}")
         if v["dielectric bodies"]:
             print(f"   dielectric block: {v['dielectric bodies'] / it:.2f} per iteration with {v['dielectric lanes'] / v['dielectric bodies']:.1f} lanes each")
 
