@@ -10,6 +10,7 @@ WIDE8_IEEE mode is the bit-exact twin and the reference image is matched statist
 import ctypes as C
 import hashlib
 import json
+import pathlib
 
 import numpy as np
 import pytest
@@ -258,6 +259,58 @@ def test_other_configurations_at_full_resolution(ctx, cornell):
     check_against_oracle(ctx, build_scene("spheres"), B.default_params(1280, 720, 128, lanes_per_pixel=2))
     check_against_oracle(ctx, build_scene("glass_spheres", 5), B.default_params(1920, 1080, 32, lanes_per_pixel=2, max_bounces=32))
     check_against_oracle(ctx, build_scene("random_spheres", 4096, 1), B.default_params(960, 540, 4, lanes_per_pixel=2))
+
+
+def _bench_config(name):
+    import bench
+    cfg = bench.CONFIGS[name]
+    return cfg, build_scene(*cfg["scene"])
+
+
+@pytest.mark.parametrize("name,size,spp", [("cornell1024", None, 64), ("cornell4k", None, 32), ("spheres", None, 512),
+                                           ("glass", None, 128), ("spheres4096", (480, 270), 32)])
+def test_benchmarked_launch_sequences_against_the_oracle(ctx, name, size, spp):
+    """Every bench.py configuration in the form bench.py launches it - its scene, image size, bounce cap, lanes per
+    pixel and RT_FLAG_COMPACT_TAILS (stage 1, stage 2, per-pixel combine) - against the CPU oracle, with the sample
+    count cut to what the oracle renders in seconds (but at least 8 samples per lane, so that the compaction runs);
+    the 4096-sphere scene also at a smaller image; the reference's spheres scene runs at its full 512 spp.  (The headline configuration at its full sample count:
+    test_compacted_bench_workload_bit_exact.)"""
+    cfg, scene = _bench_config(name)
+    w, h = size or (cfg["width"], cfg["height"])
+    assert spp // cfg["lanes"] >= 8
+    check_against_oracle(ctx, scene, B.default_params(w, h, spp, lanes_per_pixel=cfg["lanes"], max_bounces=cfg["bounces"],
+                                                      flags=B.FLAG_COMPACT_TAILS))
+
+
+@pytest.mark.parametrize("name", ["spheres", "spheres4096", "glass", "cornell1024", "cornell4k"])
+def test_benchmarked_workloads_at_full_size(ctx, name):
+    """The other bench.py configurations at their FULL size and sample count, where the oracle would take minutes
+    to hours: the compacted launch sequence that bench.py times gives the pixels and ray count of the single launch,
+    bit for bit (the single launch is the form checked against the oracle at smaller sample counts), and the ray
+    count is the one recorded with the published timings (profiles/r02_configs.jsonl)."""
+    import torch
+    cfg, scene = _bench_config(name)
+    recorded = {}
+    for line in (pathlib.Path(__file__).resolve().parent.parent / "profiles" / "r02_configs.jsonl").read_text().splitlines():
+        d = json.loads(line)
+        recorded[d["config"]["name"]] = d["config"]["rays_per_step"]
+    ctx.upload_world(scene)
+    dev = torch.device("cuda", 0)
+    w, h = cfg["width"], cfg["height"]
+    out = []
+    for flags in (B.FLAG_COMPACT_TAILS, 0):
+        p = B.default_params(w, h, cfg["spp"], lanes_per_pixel=cfg["lanes"], max_bounces=cfg["bounces"], flags=flags)
+        ctx.reserve(p)
+        pixels = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        rays = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.render_device(p, pixels.data_ptr(), None, rays.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        out.append((pixels, int(rays.item())))
+    assert out[0][1] == out[1][1], "ray count of the compacted and the single-launch render"
+    assert torch.equal(out[0][0], out[1][0])
+    if name in recorded:
+        assert out[0][1] == recorded[name]
+    assert out[0][1] > w * h * cfg["spp"]
 
 
 def test_image_statistics_match_the_reference(ctx, cornell, golden_dir):
