@@ -97,3 +97,24 @@ def test_bench_through_rccl_with_one_rank(shard):
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["shard"] == shard
     assert line["composition_check"] == {"pixels_identical_to_one_gpu_render": True, "rays_identical": True}
+
+
+@pytest.mark.parametrize("world_size,shard", [(2, "samples"), (8, "samples"), (4, "rows")])
+def test_bench_rehearsal_composes_the_one_gpu_image(world_size, shard):
+    """`python bench.py --gpus N` as the driver types it (self-launched ranks, fixed job split over them), rehearsed
+    with all ranks on this one GPU and gloo in place of RCCL: the composed image and ray count equal one GPU's
+    render of the whole job (N = 8: 128 samples per rank of 1024)."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(world_size), "--steps", "2", "--warmup", "1", "--rehearse-on-one-gpu",
+           "--shard", shard, "--width", "320", "--height", "180"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True, timeout=400, env=env).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world_size and line["scaling"] == "strong" and line["config"]["shard"] == shard
+    if shard == "samples":
+        assert line["config"]["spp_total"] == 1024 and line["config"]["spp_per_gpu"] * world_size == 1024
+    assert line["composition_check"] == {"pixels_identical_to_one_gpu_render": True, "rays_identical": True}
