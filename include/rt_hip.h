@@ -103,10 +103,9 @@ enum {  /* rt_render_params.rng_mode */
 enum {  /* rt_render_params.intersect_mode */
     RT_INTERSECT_WIDE8 = 0,   /* arithmetic and tie-breaks of IntersectWorldWide (main.cpp:26-161) at LANE_WIDTH 8 */
     RT_INTERSECT_SCALAR = 1,  /* arithmetic and order of IntersectWorld (main.cpp:163-242) */
-    RT_INTERSECT_WIDE4 = 2    /* IntersectWorldWide as a LANE_WIDTH 4 build would run it (simd.h:17-26, simd_sse.h): the same
+    RT_INTERSECT_WIDE4 = 2    /* IntersectWorldWide of the reference built at LANE_WIDTH 4 (simd.h:17-26, simd_sse.h): the same
                                  arithmetic, primitives dealt to four lanes, so closest-hit ties between primitives may fall
-                                 to another one than at width 8.  The reference fixes LANE_WIDTH at 8, so this order is
-                                 checked against a restatement only. */
+                                 to another one than at width 8 */
 };
 
 enum {  /* rt_render_params.flags */

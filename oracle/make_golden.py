@@ -9,6 +9,7 @@ counts of full-size renders.
   python oracle/make_golden.py            # small fixtures (seconds)
   python oracle/make_golden.py --full     # also the 1280x720x512 known answers (minutes)
   python oracle/make_golden.py --reference-images   # only the 320x180x64 reference radiance images (seconds)
+  python oracle/make_golden.py --lane4 [--full]     # only the fixtures of the reference built at LANE_WIDTH 4
 """
 import argparse
 import hashlib
@@ -24,6 +25,8 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 GOLDEN = ROOT / "tests" / "golden"
 STRICT = ROOT / "oracle" / "_ref" / "ref_harness_strict"   # -ffp-contract=off: the arithmetic spec
 SHIPPED = ROOT / "oracle" / "_ref" / "ref_harness"         # the reference's own flags
+STRICT4 = ROOT / "oracle" / "_ref" / "ref_harness_lane4_strict"    # the same two builds at LANE_WIDTH 4 (simd.h:20-26, simd_sse.h)
+SHIPPED4 = ROOT / "oracle" / "_ref" / "ref_harness_lane4"
 sys.path.insert(0, str(ROOT))
 
 
@@ -57,16 +60,61 @@ def reference_images():
             print("reference image", name, info["rays"], md5, flush=True)
 
 
+def update_known(known):
+    path = GOLDEN / "known_answers.json"
+    old = json.loads(path.read_text()) if path.exists() else {}
+    old.update(known)
+    path.write_text(json.dumps(old, indent=1, sort_keys=True) + "\n")
+
+
+def lane4_fixtures(full):
+    """What the reference computes when built at LANE_WIDTH 4: per-ray vectors of its 4-wide IntersectWorldWide on
+    the four fixture scenes and on a scene of exact ties, small images of the tie scene at both widths (they
+    differ: the order of the lanes decides), the 320x180x64 and - with --full - 1280x720x512 known answers."""
+    if not STRICT4.exists() or not SHIPPED4.exists():
+        raise SystemExit("build the LANE_WIDTH 4 harness first: make -C oracle ref")
+    sys.path.insert(0, str(ROOT / "tests"))
+    from raytracer_amd.scene_io import write_scene
+    from test_gpu_parity import tie_scene
+    write_scene(GOLDEN / "tie.rtsc", tie_scene())
+    known = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, scene in (("cornell", "cornell"), ("spheres", "spheres"), ("random61", GOLDEN / "random61.rtsc"),
+                            ("glass3", GOLDEN / "glass3.rtsc"), ("tie", GOLDEN / "tie.rtsc")):
+            run(STRICT4, "rays", scene, 2048, 7, GOLDEN / f"rays_{name}_lane4.bin")
+        run(STRICT, "rays", GOLDEN / "tie.rtsc", 2048, 7, GOLDEN / "rays_tie.bin")
+        for width, binary in ((8, STRICT), (4, STRICT4)):
+            info, rad, pix, _ = render(binary, GOLDEN / "tie.rtsc", 64, 36, 4, tmp)
+            np.savez_compressed(GOLDEN / f"image_tie_64x36_4spp_lane{width}.npz", radiance=rad, pixels=pix, rays=np.uint64(info["rays"]))
+        sizes = [(320, 180, 64)] + ([(1280, 720, 512)] if full else [])
+        for w, h, spp in sizes:
+            for build, binary in (("strict_lane4", STRICT4), ("asshipped_lane4", SHIPPED4)):
+                for scene in ("cornell", "spheres"):
+                    info, rad, pix, md5 = render(binary, scene, w, h, spp, tmp)
+                    known[f"{scene}_{w}x{h}_{spp}spp_{build}"] = {
+                        "rays": info["rays"], "bmp_md5": md5,
+                        "radiance_sha256": hashlib.sha256(rad.tobytes()).hexdigest(),
+                        "pixels_sha256": hashlib.sha256(pix.tobytes()).hexdigest(),
+                        "mean_radiance": [float(x) for x in rad.reshape(-1, 3).mean(axis=0, dtype=np.float64)],
+                    }
+                    print(scene, w, h, spp, build, info["rays"], md5, flush=True)
+    update_known(known)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--reference-images", action="store_true")
+    ap.add_argument("--lane4", action="store_true")
     args = ap.parse_args()
     if not STRICT.exists() or not SHIPPED.exists():
         raise SystemExit("build the reference harness first: make -C oracle ref")
     GOLDEN.mkdir(parents=True, exist_ok=True)
     if args.reference_images:
         reference_images()
+        return
+    if args.lane4:
+        lane4_fixtures(args.full)
         return
     from raytracer_amd.host_scene import build_scene
     from raytracer_amd.scene_io import write_scene
@@ -111,10 +159,8 @@ def main():
                     }
                     print(scene, w, h, spp, build, info["rays"], md5, flush=True)
     reference_images()
-    path = GOLDEN / "known_answers.json"
-    old = json.loads(path.read_text()) if path.exists() else {}
-    old.update(known)
-    path.write_text(json.dumps(old, indent=1, sort_keys=True) + "\n")
+    update_known(known)
+    lane4_fixtures(args.full)
 
 
 if __name__ == "__main__":

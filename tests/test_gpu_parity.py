@@ -125,6 +125,18 @@ def test_cornell_full_size_known_answer(ctx, cornell, golden_dir):
     assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
 
 
+def test_cornell_full_size_known_answer_at_lane_width_four(ctx, cornell, golden_dir):
+    """The same render as the reference BUILT AT LANE_WIDTH 4 produces it (simd.h:20-26; its closest-hit ties fall to
+    other rectangles than at width 8: 24 rays fewer): RT_INTERSECT_WIDE4 must hash to that radiance image."""
+    known = json.loads((golden_dir / "known_answers.json").read_text())
+    k = known["cornell_1280x720_512spp_strict_lane4"]
+    ctx.upload_world(cornell)
+    pix, rad, rays = ctx.render(B.default_params(1280, 720, 512, rng_mode=B.RNG_ROW_SERIAL, intersect_mode=B.INTERSECT_WIDE4))
+    assert rays == k["rays"] != known["cornell_1280x720_512spp_strict"]["rays"]
+    assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
+    assert hashlib.sha256(O.pack_srgb(rad).tobytes()).hexdigest() == k["pixels_sha256"]
+
+
 def test_spheres_full_size_scalar_routine(ctx, spheres, golden_dir):
     """Spheres + plane at 1280x720x512 (the reference's spheres scene at the size it ships).  WIDE8 differs from the reference only in
     the sphere-normal rsqrt, so the image matches statistically; mean radiance within 0.5 %."""
@@ -626,6 +638,21 @@ def test_ties_between_primitives_follow_the_lane_order(ctx):
     # wins); at width 4 index 4 shares lane 0 with the farther index 0, replaces it there, and lane 0 goes first
     assert np.array_equal(images[B.INTERSECT_SCALAR], images[B.INTERSECT_WIDE8])
     assert not np.array_equal(images[B.INTERSECT_WIDE4], images[B.INTERSECT_WIDE8])
+
+
+@pytest.mark.parametrize("width,imode", [(8, B.INTERSECT_WIDE8), (4, B.INTERSECT_WIDE4)])
+def test_tie_scene_against_the_reference_at_both_lane_widths(ctx, golden_dir, width, imode):
+    """The tie scene as the reference itself renders it, built at LANE_WIDTH 8 and at LANE_WIDTH 4 (two different
+    images): the GPU's row-stream render in the matching mode is that image bit for bit; and the 2048 tie-scene
+    rays' winners are those of the reference's 4-wide routine (through a one-bounce render of each... the oracle
+    holds the per-ray vectors, tests/test_oracle_golden.py)."""
+    g = np.load(golden_dir / f"image_tie_64x36_4spp_lane{width}.npz")
+    scene = scene_io.read_scene(golden_dir / "tie.rtsc")
+    assert np.array_equal(scene.rectangles.tobytes(), tie_scene().rectangles.tobytes())
+    ctx.upload_world(scene)
+    pix, rad, rays = ctx.render(B.default_params(64, 36, 4, rng_mode=B.RNG_ROW_SERIAL, intersect_mode=imode))
+    assert rays == int(g["rays"]) and np.array_equal(bits(rad), bits(g["radiance"]))
+    assert_pixels_close(pix, g["pixels"])
 
 
 # ---------------------------------------------------------------- sums, passes and their composition, against the oracle

@@ -97,6 +97,43 @@ def test_intersection_vectors(golden_dir, scenes, name):
                 assert np.array_equal(bits(n), bits(r[f"{p}_n"]))
 
 
+@pytest.mark.parametrize("name", SCENES + ["tie"])
+def test_intersection_vectors_at_lane_width_four(golden_dir, name):
+    """IntersectWorldWide of the reference BUILT AT LANE_WIDTH 4 (simd.h:20-26, simd_sse.h; oracle/Makefile,
+    ref_harness_lane4_strict) on 2048 rays per scene, bit for bit - including a scene of exact ties between
+    rectangles, where the winner depends on the lane order, at width 4 and at the shipped width 8."""
+    scene = read_scene(golden_dir / f"{name}.rtsc")
+    osc = O.OracleScene(scene)
+    cases = [(f"rays_{name}_lane4.bin", (O.WIDE4,))]
+    if name == "tie":
+        cases.append(("rays_tie.bin", (O.WIDE8, O.WIDE8_AVX2, O.WIDE8_LANES)))
+    winners = {}
+    for file, modes in cases:
+        rays = np.fromfile(golden_dir / file, dtype=RAY)
+        assert len(rays) == 2048 and rays["wide_hit"].sum() > 200
+        winners[file] = rays["wide_mat"][rays["wide_hit"] != 0]
+        for r in rays:
+            for mode in modes:
+                hit, t, mat, n = osc.intersect(mode, r["o"], r["d"])
+                assert hit == bool(r["wide_hit"]) and bits(t) == bits(r["wide_t"])
+                if hit:
+                    assert mat == r["wide_mat"] and np.array_equal(bits(n), bits(r["wide_n"]))
+    if name == "tie":   # the two widths really disagree on who wins the ties
+        assert not np.array_equal(winners["rays_tie_lane4.bin"], winners["rays_tie.bin"])
+
+
+@pytest.mark.parametrize("width,modes", [(8, (O.WIDE8, O.WIDE8_AVX2, O.WIDE8_LANES, O.WIDE8_IEEE)), (4, (O.WIDE4, O.WIDE4_IEEE))])
+def test_tie_scene_images_at_both_lane_widths(golden_dir, width, modes):
+    """The reference's own renders of the tie scene, built at LANE_WIDTH 8 and at LANE_WIDTH 4 (different images)."""
+    g = np.load(golden_dir / f"image_tie_64x36_4spp_lane{width}.npz")
+    other = np.load(golden_dir / f"image_tie_64x36_4spp_lane{12 - width}.npz")
+    assert not np.array_equal(g["radiance"], other["radiance"])
+    scene = read_scene(golden_dir / "tie.rtsc")
+    for mode in modes:
+        pix, rad, rays = O.OracleScene(scene).render(O.default_params(64, 36, 4, intersect_mode=mode), threads=4)
+        assert rays == int(g["rays"]) and np.array_equal(bits(rad), bits(g["radiance"])) and np.array_equal(pix, g["pixels"])
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_path_vectors(golden_dir, scenes, name):
     """RaytraceWorld of the reference on 1024 paths: radiance, final RNG state, bounce count."""
@@ -160,12 +197,23 @@ def test_known_answers_320x180(golden_dir, scenes, name, tmp_path):
     assert hashlib.md5((tmp_path / "render.bmp").read_bytes()).hexdigest() == k["bmp_md5"]
 
 
-@pytest.mark.slow
 @pytest.mark.parametrize("name", ["cornell", "spheres"])
-def test_known_answers_full_size(golden_dir, scenes, name):
-    """1280x720 at 512 spp, the size the reference ships (main.cpp:410,415)."""
-    k = _known(golden_dir)[f"{name}_1280x720_512spp_strict"]
-    pix, rad, rays = O.OracleScene(scenes[name]).render(O.default_params(1280, 720, 512, intersect_mode=O.WIDE8_AVX2))
+def test_known_answers_320x180_at_lane_width_four(golden_dir, scenes, name):
+    k = _known(golden_dir)[f"{name}_320x180_64spp_strict_lane4"]
+    pix, rad, rays = O.OracleScene(scenes[name]).render(O.default_params(320, 180, 64, intersect_mode=O.WIDE4))
+    assert rays == k["rays"]
+    assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
+    assert hashlib.sha256(pix.tobytes()).hexdigest() == k["pixels_sha256"]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("lane4", [False, True])
+@pytest.mark.parametrize("name", ["cornell", "spheres"])
+def test_known_answers_full_size(golden_dir, scenes, name, lane4):
+    """1280x720 at 512 spp, the size the reference ships (main.cpp:410,415), at its lane width 8 and built at 4
+    (where some closest-hit ties fall to another rectangle: the two Cornell renders differ in ray count)."""
+    k = _known(golden_dir)[f"{name}_1280x720_512spp_strict" + ("_lane4" if lane4 else "")]
+    pix, rad, rays = O.OracleScene(scenes[name]).render(O.default_params(1280, 720, 512, intersect_mode=O.WIDE4 if lane4 else O.WIDE8_AVX2))
     assert rays == k["rays"]
     assert hashlib.sha256(rad.tobytes()).hexdigest() == k["radiance_sha256"]
     assert hashlib.sha256(pix.tobytes()).hexdigest() == k["pixels_sha256"]
@@ -178,6 +226,12 @@ def test_reference_known_answers_recorded(golden_dir):
     assert k["cornell_1280x720_512spp_asshipped"]["bmp_md5"] == "48f0c10b0f76b2612a96a0ed0d2bb5e7"
     assert k["spheres_1280x720_512spp_asshipped"]["rays"] == 1120169035
     assert k["spheres_1280x720_512spp_asshipped"]["bmp_md5"] == "8584d8cc20e4611c44852efa64b3a660"
+    # ... and built at LANE_WIDTH 4 (the SSE path): the survey's known answers for that build
+    assert k["cornell_1280x720_512spp_asshipped_lane4"]["rays"] == 1293033753
+    assert k["cornell_1280x720_512spp_asshipped_lane4"]["bmp_md5"] == "40f206ddc0d59665ddafb71fba5f1d7e"
+    assert k["spheres_1280x720_512spp_asshipped_lane4"]["rays"] == 1120169035
+    assert k["spheres_1280x720_512spp_asshipped_lane4"]["bmp_md5"] == "8584d8cc20e4611c44852efa64b3a660"
+    assert k["cornell_1280x720_512spp_strict_lane4"]["rays"] != k["cornell_1280x720_512spp_strict"]["rays"]
 
 
 # ---- properties of the modes that have no counterpart in the reference ------------------

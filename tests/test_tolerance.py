@@ -90,10 +90,10 @@ def test_oracle_reproduces_the_reference_images(golden_dir, name):
 
 @pytest.mark.parametrize("name", SCENES)
 def test_lane_width_four_gives_the_reference_images_too(golden_dir, name):
-    """The reference fixes LANE_WIDTH at 8 (simd.h:17), so its 4-wide order cannot be rendered by the reference
-    itself.  What can be pinned: the width-generic restatement at width 8 is the pinned 8-wide routine bit for
-    bit, and at width 4 it still reproduces the reference's images of its own scenes (no tie between lanes
-    decides a pixel there).  Only the outcome of exact ties at width 4 rests on the restatement alone."""
+    """The width-generic restatement at width 8 is the pinned 8-wide routine bit for bit, and at width 4 it still
+    reproduces the reference's LANE_WIDTH 8 images of these scenes at this size (no tie between lanes decides a
+    pixel here).  Where ties do decide - the tie scene, the Cornell box at 1280x720 - the width-4 order is pinned
+    against the reference built at LANE_WIDTH 4 (tests/test_oracle_golden.py)."""
     scene, ref_rad, ref_pix, ref_rays = load(golden_dir, name)
     for mode in (O.WIDE8_LANES, O.WIDE4):
         pix, rad, rays = O.OracleScene(scene).render(O.default_params(320, 180, 64, intersect_mode=mode))
