@@ -417,7 +417,13 @@ def main():
         compacted = not args.no_compact and spp // B_lanes >= 8       # the library's rule (rt_api.hip)
         key = f"{args.config}_{W}x{H}_{spp}spp" + ("" if compacted else "_single_launch") + ("_no_cull" if args.no_cull else "")
         traffic = profile.get(key) if world_size == 1 and B_lanes == cfg["lanes"] else None
-        pairs = profile.get("rect_pairs_tested_per_ray", {}).get(args.config) if not args.no_cull else None
+        pairs = None
+        cfile = ROOT / "profiles" / "cull_stats.json"
+        if cfile.exists() and not args.no_cull:
+            try:
+                pairs = json.loads(cfile.read_text())["rect_pairs_tested_per_ray"].get("cornell" if args.config.startswith("cornell") else args.config)
+            except (ValueError, OSError, KeyError):
+                pairs = None
         label = cfg["label"] if (W, H) == (cfg["width"], cfg["height"]) else f"{cfg['label'].rsplit(' ', 1)[0]} {W}x{H}"
         if rows_mode:
             workload = f"{label} {spp} spp, interleaved 8-row bands over {world_size} GPUs, RCCL all_gather"
@@ -448,7 +454,7 @@ def main():
                        "device": info.name.decode(), "compute_units": info.compute_units, "clock_mhz": info.clock_khz / 1e3},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 TCC_EA0_RDREQ / TCC_EA0_WRREQ byte counts of this command, "
+                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of one render with this launch sequence, "
                                            "collected in separate --pmc passes, not measured by this run)" if traffic else None,
                          "flop_per_ray": flop_per_ray, "flop_terms": flop_terms,
                          "rect_pairs_tested_per_ray": pairs, "kernel_ms": round(kernel_ms, 3),

@@ -91,13 +91,22 @@ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 // still have work and none of them has more than `pool_max_samples()` samples left to start.  The second
 // bound keeps the handed-over streams short: stage 2 only begins when stage 1 has ended, so a long stream
 // would run there on its own (measured on the Cornell bench without it: stage 1 -1.1 ms, stage 2 +1.6 ms).
-// Defaults from a sweep on the bench (T 16..48 x S 2..32); the environment variables are for experiments.
+// Defaults from a sweep on the bench (T 16..48 x S 2..32).
 // A lane with few samples hands over at most a quarter of them: the bound is min(12, samples_per_lane / 4 - 1),
 // and renders with fewer than 8 samples per lane run as one launch (4096 spheres at 64 spp: 4 lanes per pixel
 // with 16 samples each and a bound of 3 take 498 ms, one lane per pixel with the bound of 12 takes 566 ms).
+//
+// The shipped library reads nothing from the environment.  Only a build with -DRT_EXPERIMENT_KNOBS (make knobs,
+// used by the sweep scripts) lets RT_POOL_THRESHOLD, RT_POOL_MAX_SAMPLES, RT_BLOCK_THREADS and
+// RT_STAGE2_WAVES_PER_CU override these launch parameters.
 uint32_t env_or(const char* name, long fallback, long lo, long hi) {
+#ifdef RT_EXPERIMENT_KNOBS
     const char* env = std::getenv(name);
     long v = env ? std::strtol(env, nullptr, 10) : fallback;
+#else
+    (void)name;
+    long v = fallback;
+#endif
     return (uint32_t)(v < lo ? lo : v > hi ? hi : v);
 }
 uint32_t pool_threshold() { static const uint32_t v = env_or("RT_POOL_THRESHOLD", 32, 1, 63); return v; }
@@ -552,13 +561,13 @@ const char* rt_status_string(rt_status status) {
         case RT_ERR_NO_DEVICE: return "no usable HIP device";
         case RT_ERR_HIP: return "HIP runtime error";
         case RT_ERR_NO_WORLD: return "no world uploaded";
-        case RT_ERR_TOO_LARGE: return "scene too large for LDS";
+        case RT_ERR_TOO_LARGE: return "too large (planes, rectangles and materials for the LDS of a workgroup, or a render for the fixed workspace of rt_render_device_noalloc)";
         case RT_ERR_OUT_OF_MEMORY: return "out of device memory";
     }
     return "unknown status";
 }
 
-rt_status rt_create(int device_ordinal, rt_context** out_context) {
+static rt_status create_impl(int device_ordinal, rt_context** out_context) {
     if (!out_context) return RT_ERR_INVALID_ARGUMENT;
     *out_context = nullptr;
     int count = 0;
@@ -597,10 +606,14 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
     (void)hipFree(d_warm);
     // This device's copy of the fixed workspace (see `scratch`): looked up once per device, with that device current.
     {
+        constexpr int MAX_DEVICES = 256;
         static std::mutex lookup_mutex;
-        static std::vector<unsigned char*> per_device;
+        static unsigned char* per_device[MAX_DEVICES] = {};     // no heap: nothing here can throw bad_alloc
+        if (device_ordinal >= MAX_DEVICES) {
+            rt_destroy(ctx);
+            return RT_ERR_NO_DEVICE;
+        }
         std::lock_guard<std::mutex> lock(lookup_mutex);
-        if (per_device.size() < (size_t)count) per_device.resize((size_t)count, nullptr);
         if (!per_device[device_ordinal]) {
             void* address = nullptr;
             if (hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)) != hipSuccess || !address) {
@@ -613,6 +626,10 @@ rt_status rt_create(int device_ordinal, rt_context** out_context) {
     }
     *out_context = ctx;
     return RT_OK;
+}
+
+rt_status rt_create(int device_ordinal, rt_context** out_context) {
+    return guarded([&] { return create_impl(device_ordinal, out_context); });   // std::mutex may throw system_error
 }
 
 void rt_destroy(rt_context* ctx) {
@@ -745,7 +762,10 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
             return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "rt_upload_world: %s", hipGetErrorString(e));
         }
     }
-    RT_HIP_CHECK(ctx, hipDeviceSynchronize());   // no render may still read the old images
+    if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) {   // no render may still read the old images
+        for (int j = 0; j < 3; ++j) (void)hipFree(fresh[j]);
+        return fail(ctx, RT_ERR_HIP, "rt_upload_world: %s", hipGetErrorString(e));
+    }
     for (int i = 0; i < 3; ++i) {
         if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
         ctx->d_image[i] = fresh[i];
@@ -760,11 +780,12 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     ctx->has_world = true;
     ctx->accumulator_valid = false;
     // Size stage 2 for this world's kernel variants now (an occupancy query each), so that no later launch -
-    // a captured one, or the entry point that must not allocate - is the first to ask.
+    // a captured one, or the entry point that must not allocate - is the first to ask.  Best effort: the world
+    // is in place, and a failed query only means the default of 16 waves per CU (stage2_waves_per_cu).
     for (int imode : {RT_INTERSECT_WIDE8, RT_INTERSECT_SCALAR}) {
         Launch L;
         L.imode = imode; L.rmode = RT_RNG_PIXEL; L.blocks = 1; L.block_threads = workgroup_threads(ctx);
-        RT_HIP_CHECK(ctx, launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true));
+        (void)launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true);
     }
     return RT_OK;
 }

@@ -420,7 +420,10 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         const float a = IMODE == RT_INTERSECT_WIDE8 ? dot_fma(d, d) : dot(d, d);
         const float denom = 2.0f * a;
         const float minus_four_a = -4.0f * a;   // -(4a * c) is (-4a) * c: negation commutes with the rounding
-        // b = 2 * dot(d, cto) is computed as dot(2d, cto): scaling by two commutes with every rounding.
+        // b = 2 * dot(d, cto) is computed as dot(2d, cto): scaling by two commutes with every rounding, unless a
+        // product or partial sum is subnormal (a direction component times a centre offset below 1.2e-38, say
+        // 1e-30 x 1e-9): such a term's last bit can then differ from the reference's, which reaches b only when all
+        // three terms are that small.  The same precondition holds for minus_four_a * c above.
         const V3 d2 = mk(2.0f * d.x, 2.0f * d.y, 2.0f * d.z);
         // Both roots are divided by the same 2a: the reciprocal estimate and its Newton step (the
         // first three operations of the IEEE division refinement, see div2) are done once per ray.

@@ -1,4 +1,6 @@
 # Runs on the GPU box: one configuration (CFG, default glass) over lanes per pixel and hand-over bounds, compacted and single launch.
+# The RT_* launch knobs exist only in the experiment build: make -C raytracer_amd/csrc knobs, then RT_HIP_LIBRARY=$PWD/build/librt_hip_knobs.so
+export RT_HIP_LIBRARY=${RT_HIP_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/build/librt_hip_knobs.so}
 set -e
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 run() { echo "== $*"; env "$@" CONFIG_LIST="${CFG:-glass}" STEPS=3 bash scripts/job_configs.sh sweep | tail -1; }

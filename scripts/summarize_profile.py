@@ -13,6 +13,10 @@ rays = int(sys.argv[4]) if len(sys.argv) > 4 else 1454628861
 flop_per_ray = float(sys.argv[5]) if len(sys.argv) > 5 else 887
 command = sys.argv[6] if len(sys.argv) > 6 else "--scene cornell --width 1920 --height 1080 --spp 256"
 
+import re
+_w, _h = re.search(r"--width (\d+)", command), re.search(r"--height (\d+)", command)
+width, height = int(_w.group(1)) if _w else 1920, int(_h.group(1)) if _h else 1080
+
 lines = [f"# {title}", "", "Command (per pass): `rocprofv3 <--kernel-trace --stats | --pmc ...> -- raytracer_amd/bin/raytracer "
          f"{command}` (scripts/profile_gpu.sh).", ""]
 stats = list(csv.DictReader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))))
@@ -60,7 +64,8 @@ if kernel_ns:
         fetch = c["FETCH_SIZE"] * 1024 * 2
         write = c["WRITE_SIZE"] * 1024
         d.append(f"HBM traffic: FETCH_SIZE {c['FETCH_SIZE']:.1f} KiB (x2 gfx950 correction = {fetch / 1e6:.2f} MB), WRITE_SIZE {c['WRITE_SIZE']:.1f} KiB "
-                 f"({write / 1e6:.2f} MB); algorithmic output 1920x1080x4 B = 8.29 MB; {(fetch + write) / (kernel_ns * 1e-9) / 1e9:.2f} GB/s of ~8000")
+                 f"({write / 1e6:.2f} MB) = {(fetch + write) / 1e6:.2f} MB per render; algorithmic output {width}x{height}x4 B = {width * height * 4 / 1e6:.2f} MB "
+                 f"(ratio {(fetch + write) / (width * height * 4):.1f}); {(fetch + write) / (kernel_ns * 1e-9) / 1e9:.2f} GB/s of ~8000")
 lines += ["", "## derived", ""] + [f"- {x}" for x in d]
 open(dst, "w").write("\n".join(lines) + "\n")
 print("\n".join(d))

@@ -1,6 +1,7 @@
 """Kernel time of the compacted Cornell bench render for the lanes-per-pixel values given as first argument
 (comma separated); RT_POOL_THRESHOLD / RT_POOL_MAX_SAMPLES in the environment select the hand-over bounds.
-Run on the GPU box, e.g.  RT_POOL_MAX_SAMPLES=8 python scripts/sweep_compaction.py 2,4"""
+Run on the GPU box with the experiment build of the library (make -C raytracer_amd/csrc knobs), e.g.
+RT_HIP_LIBRARY=$PWD/build/librt_hip_knobs.so RT_POOL_MAX_SAMPLES=8 python scripts/sweep_compaction.py 2,4"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repository root
 from raytracer_amd import binding as B
