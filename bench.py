@@ -172,7 +172,7 @@ def cpu_baseline(config_name, cfg, width, height, spp, threads):
         value, seconds, rays = max(runs)
         result = {"value": round(value, 2), "unit": "Mrays/s", "cores": threads, "cores_online": online, "cpu_model": cpu_model(),
                   "kind": "reference" if use_reference else "port",
-                  "sample": f"{cfg['label'].rsplit(' ', 1)[0]} {width}x{height} at {spp} spp, {cfg['bounces']} bounces, "
+                  "sample": f"{cfg['label'].rsplit(' ', 1)[0].replace(', 32 bounces,', '')} {width}x{height} at {spp} spp, {cfg['bounces']} bounces, "
                             f"{rays} rays, one row per work order, AVX2 lanes, best of {len(runs)}",
                   "spp": spp, "seconds": round(seconds, 2), "runs_mrays_per_s": [round(r[0], 2) for r in runs]}
         if threads != 16 and online >= 16:

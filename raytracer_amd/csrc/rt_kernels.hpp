@@ -629,11 +629,17 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         unsigned long long todo = n_pairs >= 64u ? primary_pairs : primary_pairs & ((1ull << n_pairs) - 1ull);
         st.count(CT_RECT_PAIRS_SKIPPED, (n_pairs < 64u ? n_pairs : 64u) - (unsigned long long)__builtin_popcountll(todo));
         st.count(CT_RECT_PAIR_RAYS, RT_LANES(active) * ((unsigned long long)__builtin_popcountll(todo) + (n_pairs > 64u ? n_pairs - 64u : 0u)));
-        while (todo) {
-            test_pair((uint32_t)__builtin_ctzll(todo), std::true_type());
-            todo &= todo - 1ull;
+        // (one loop for the masked pairs and for those beyond the mask: one copy of the body)
+        uint32_t pair = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
+        while (pair < n_pairs) {
+            test_pair(pair, std::true_type());
+            if (pair < 64u) {
+                todo &= todo - 1ull;
+                pair = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
+            } else {
+                ++pair;
+            }
         }
-        for (uint32_t pair = 64; pair < n_pairs; ++pair) test_pair(pair, std::true_type());
     } else {
         st.count(CT_RECT_PAIR_RAYS, RT_LANES(active) * n_pairs);
         for (uint32_t pair = 0; pair < n_pairs; ++pair) test_pair(pair, std::false_type());
