@@ -99,7 +99,7 @@ def test_bench_through_rccl_with_one_rank(shard):
     assert line["composition_check"] == {"pixels_identical_to_one_gpu_render": True, "rays_identical": True}
 
 
-@pytest.mark.parametrize("world_size,shard", [(2, "samples"), (8, "samples"), (4, "rows")])
+@pytest.mark.parametrize("world_size,shard", [(2, "samples"), (4, "samples"), (8, "samples"), (4, "rows")])
 def test_bench_rehearsal_composes_the_one_gpu_image(world_size, shard):
     """`python bench.py --gpus N` as the driver types it (self-launched ranks, fixed job split over them), rehearsed
     with all ranks on this one GPU and gloo in place of RCCL: the composed image and ray count equal one GPU's
