@@ -294,18 +294,22 @@ def test_benchmarked_launch_sequences_against_the_oracle(ctx, name, size, spp):
                                                       flags=B.FLAG_COMPACT_TAILS))
 
 
-@pytest.mark.parametrize("name", ["spheres", "spheres4096", "glass", "cornell1024", "cornell4k"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "spheres4096", "glass", "cornell1024", "cornell4k"])
 def test_benchmarked_workloads_at_full_size(ctx, name):
-    """The other bench.py configurations at their FULL size and sample count, where the oracle would take minutes
-    to hours: the compacted launch sequence that bench.py times gives the pixels and ray count of the single launch,
-    bit for bit (the single launch is the form checked against the oracle at smaller sample counts), and the ray
-    count is the one recorded with the published timings (profiles/r02_configs.jsonl)."""
+    """The bench.py configurations at their FULL size and sample count: the compacted launch sequence that bench.py
+    times gives the pixels and ray count of the single launch, bit for bit, and the ray count is the CPU oracle's for
+    the whole job.  (The oracle needs up to ten minutes for one of these renders, so its full-size runs are a script,
+    scripts/verify_full_configs.py, whose record - radiance bit for bit, ray counts - is profiles/r03_full_size_parity.jsonl.)"""
     import torch
     cfg, scene = _bench_config(name)
     recorded = {}
-    for line in (pathlib.Path(__file__).resolve().parent.parent / "profiles" / "r02_configs.jsonl").read_text().splitlines():
+    for line in (pathlib.Path(__file__).resolve().parent.parent / "profiles" / "r03_full_size_parity.jsonl").read_text().splitlines():
         d = json.loads(line)
-        recorded[d["config"]["name"]] = d["config"]["rays_per_step"]
+        assert d["rays_gpu"] == d["rays_oracle"] and d["radiance_values_differing"] == 0 and d["rows"] == [0, d["height"]]
+        its = _bench_config(d["config"])[0]
+        assert (d["width"], d["height"], d["spp"], d["lanes_per_pixel"], d["max_bounces"]) == \
+            (its["width"], its["height"], its["spp"], its["lanes"], its["bounces"])
+        recorded[d["config"]] = d["rays_oracle"]
     ctx.upload_world(scene)
     dev = torch.device("cuda", 0)
     w, h = cfg["width"], cfg["height"]
@@ -320,8 +324,7 @@ def test_benchmarked_workloads_at_full_size(ctx, name):
         out.append((pixels, int(rays.item())))
     assert out[0][1] == out[1][1], "ray count of the compacted and the single-launch render"
     assert torch.equal(out[0][0], out[1][0])
-    if name in recorded:
-        assert out[0][1] == recorded[name]
+    assert out[0][1] == recorded[name]
     assert out[0][1] > w * h * cfg["spp"]
 
 
