@@ -930,7 +930,10 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
         // Worlds with spheres: every lane of the wave enters the intersection (the lanes stage the sphere
         // records together), lanes without a ray only help with that.
-        const bool camera_origin = __ballot(in_path && bounce != 0) == 0ull;   // all rays of the wave are primary rays
+        // All rays of the wave are primary rays?  (Not asked in STAGE 2, whose waves hold streams of many tiles in
+        // the middle of their paths: without the all-primary copy of the rectangle loop that kernel keeps a wave
+        // per SIMD more; computing the origin rows gives the bits the stored ones have.)
+        const bool camera_origin = STAGE != 2 && __ballot(in_path && bounce != 0) == 0ull;
         Closest c;
         st.count(CT_ITERATIONS, 1);
         st.count(CT_LANES_TRACING, RT_LANES(in_path));
