@@ -826,6 +826,11 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                                               global_row(p, min(ly0 + p.tile_h, p.local_rows) - 1u));
         }
     }
+    // The mask is the same in every lane (a ballot), but it was assigned under conditions derived from the thread
+    // index, which the compiler cannot see to be wave-uniform: say so, or the loop over its bits is compiled as a
+    // per-lane loop in vector registers.
+    primary_pairs = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(primary_pairs >> 32)) << 32) |
+                    __builtin_amdgcn_readfirstlane((uint32_t)primary_pairs);
     // STAGE 2: persistent waves; every lane fetches deposited streams from the pool until it is empty.
     const uint32_t pool_count = STAGE == 2 ? min(ws.pool_count[0], p.pool_capacity) : 0u;
     float film_x = 0.0f, film_y = 0.0f;
@@ -840,8 +845,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     uint32_t bounce = 0;
     bool in_path = false;                 // the lane has a ray to intersect in this iteration
     bool need_sample = has_pixel;         // the lane's previous path ended (or it has not started one)
-    unsigned long long ray_count = 0;
-    uint32_t pixel_rays = 0;
+    unsigned long long wave_rays = 0;     // rays traced by the wave: the lanes with a ray, added up every iteration (a scalar)
     if (STAGE == 2) need_sample = true;   // every lane starts by fetching a stream
 
     // STAGE 2: the pool is dealt to the waves in groups of 64 entries, group g to wave g mod (number of
@@ -867,8 +871,6 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             if (samples_left == 0) {
                 if (RMODE == RT_RNG_ROW_SERIAL) {
                     emit_pixel(p, pixel_sum, (size_t)ly * p.width + x, pixels, radiance);
-                    ray_count += pixel_rays;
-                    pixel_rays = 0;
                     pixel_sum = mk(0.0f, 0.0f, 0.0f);
                     if (++x == p.width) {
                         x = 0;
@@ -927,6 +929,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             __ballot(in_path && samples_left > p.pool_max_samples) == 0ull)
             break;   // hand the tail over: few lanes left, each with little left to do
 
+        wave_rays += (uint32_t)__builtin_popcountll(active);   // every lane with a ray traces it in this iteration (main.cpp:278)
+
         // ---- one ray per lane: a primary ray or a bounce (main.cpp:275-330) ------------------
         // Worlds with spheres: every lane of the wave enters the intersection (the lanes stage the sphere
         // records together), lanes without a ray only help with that.
@@ -948,7 +952,6 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
                 st.mark(ST_CONTROL);
                 c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, primary_pairs, true, st);
             }
-            ++pixel_rays;
             ++bounce;
             st.count(CT_HIT_LANES, RT_LANES(c.id != 0));
             if (c.id != 0) {
@@ -1002,7 +1005,6 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     }
 
     // ---- epilogue ------------------------------------------------------------------
-    ray_count += pixel_rays;
     bool pixel_pending = false;           // STAGE 1: some stream of the lane's pixel was handed over
     if (RMODE == RT_RNG_PIXEL && STAGE != 0) {
         // Finished streams leave their sum, unfinished ones (STAGE 1 only) their state.
@@ -1048,8 +1050,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     st.mark(ST_EPILOGUE);
     st.flush();
     // Ray counter: one 64-bit atomic per wave (main.cpp:397).
-    for (int offset = 32; offset > 0; offset >>= 1) ray_count += __shfl_down(ray_count, offset);
-    if ((threadIdx.x & 63) == 0 && ray_count != 0 && rays) atomicAdd(rays, ray_count);
+    if ((threadIdx.x & 63) == 0 && wave_rays != 0 && rays) atomicAdd(rays, wave_rays);
 }
 
 // Zeroes the ray counter (and the pool fill count) ahead of a render: a kernel rather than a memset
