@@ -226,7 +226,7 @@ def test_reference_known_answers_recorded(golden_dir):
     assert k["cornell_1280x720_512spp_asshipped"]["bmp_md5"] == "48f0c10b0f76b2612a96a0ed0d2bb5e7"
     assert k["spheres_1280x720_512spp_asshipped"]["rays"] == 1120169035
     assert k["spheres_1280x720_512spp_asshipped"]["bmp_md5"] == "8584d8cc20e4611c44852efa64b3a660"
-    # ... and built at LANE_WIDTH 4 (the SSE path): the survey's known answers for that build
+    # ... and built at LANE_WIDTH 4 (the SSE path): the ray counts and image hashes known for that build
     assert k["cornell_1280x720_512spp_asshipped_lane4"]["rays"] == 1293033753
     assert k["cornell_1280x720_512spp_asshipped_lane4"]["bmp_md5"] == "40f206ddc0d59665ddafb71fba5f1d7e"
     assert k["spheres_1280x720_512spp_asshipped_lane4"]["rays"] == 1120169035
