@@ -831,6 +831,8 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     // per-lane loop in vector registers.
     primary_pairs = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(primary_pairs >> 32)) << 32) |
                     __builtin_amdgcn_readfirstlane((uint32_t)primary_pairs);
+    const bool nothing_for_primary_rays = PRIMS == PRIMS_RECTS && sv.n_planes == 0 && sv.n_rects <= 128u &&
+                                          (primary_pairs & (sv.n_rects >= 128u ? ~0ull : (1ull << (sv.n_rects / 2u)) - 1ull)) == 0ull;
     // STAGE 2: persistent waves; every lane fetches deposited streams from the pool until it is empty.
     const uint32_t pool_count = STAGE == 2 ? min(ws.pool_count[0], p.pool_capacity) : 0u;
     float film_x = 0.0f, film_y = 0.0f;
@@ -948,9 +950,16 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         }
         if (in_path) {
             if (!(PRIMS & PRIMS_SPHERES)) {
-                rd = normalize(next_dir);
-                st.mark(ST_CONTROL);
-                c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, primary_pairs, true, st);
+                if (PRIMS == PRIMS_RECTS && camera_origin && nothing_for_primary_rays) {
+                    // Primary rays of a tile from which no rectangle can be reached (and a world without planes): a
+                    // miss, whatever the direction; the miss branch below does not read it, so it is not normalised.
+                    c.t = 3.402823466e+38f;
+                    c.id = 0;
+                } else {
+                    rd = normalize(next_dir);
+                    st.mark(ST_CONTROL);
+                    c = intersect_world<IMODE, PRIMS>(sv, ro, rd, p.min_hit, p.plane_tol, camera_origin, primary_pairs, true, st);
+                }
             }
             ++bounce;
             st.count(CT_HIT_LANES, RT_LANES(c.id != 0));
