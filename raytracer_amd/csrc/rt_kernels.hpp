@@ -28,6 +28,10 @@
 
 namespace rt {
 
+// The lanes of the wave for which `predicate` holds.  (The compiler's own ballot takes the predicate as a mask
+// in scalar registers; hip's __ballot goes through an integer per lane and a vector compare.)
+__device__ __forceinline__ unsigned long long ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
+
 struct KernelParams {
     uint32_t width, height, spp;
     uint32_t local_rows, row_begin, band_rows, band_index, band_count;
@@ -74,7 +78,7 @@ __device__ unsigned long long rt_stamp_table[ST_COUNT];
 struct Stamps {
     unsigned long long* slot;   // [ST_COUNT + 1] of this wave; the last word is the time of the previous mark
     __device__ __forceinline__ bool first_active() const {
-        return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true));
+        return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ballot(true));
     }
     __device__ __forceinline__ void begin() {
         __shared__ unsigned long long table[MAX_STAMP_WAVES][ST_COUNT + 1];
@@ -94,7 +98,7 @@ struct Stamps {
             for (int i = 0; i < ST_COUNT; ++i) atomicAdd(&rt_stamp_table[i], slot[i]);
     }
 };
-#define RT_LANES(pred) ((unsigned long long)__builtin_popcountll(__ballot(pred)))
+#define RT_LANES(pred) ((unsigned long long)__builtin_popcountll(ballot(pred)))
 #else
 struct Stamps {
     __device__ __forceinline__ void begin() {}
@@ -378,7 +382,7 @@ __device__ __forceinline__ unsigned long long primary_pair_mask(const double* __
         const bool below = all_pos ? highest(rec + CULL_BELOW) < 0.0 : lowest(rec + CULL_BELOW) > 0.0;
         if (!(right || left || above || below)) keep = true;
     }
-    return __ballot(keep);
+    return ballot(keep);
 }
 
 // `camera_origin` (wave-uniform): every lane's ray starts at the camera position, so the rectangles'
@@ -597,8 +601,8 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         // How often could a wave skip work here?  Pairs whose two planes lie behind every ray of the wave
         // (t <= 0 on all lanes), and rectangles that no lane's t passes min_hit < t < closest so far.
         st.count(CT_RECT_PAIRS, 1);
-        st.count(CT_RECT_PAIRS_BEHIND, __ballot(t2.x > 0.0f || t2.y > 0.0f) == 0ull ? 1 : 0);
-        st.count(CT_RECTS_OUT_OF_RANGE, (__ballot(t2.x > min_hit && t2.x < best_t) == 0ull ? 1 : 0) + (__ballot(t2.y > min_hit && t2.y < best_t) == 0ull ? 1 : 0));
+        st.count(CT_RECT_PAIRS_BEHIND, ballot(t2.x > 0.0f || t2.y > 0.0f) == 0ull ? 1 : 0);
+        st.count(CT_RECTS_OUT_OF_RANGE, (ballot(t2.x > min_hit && t2.x < best_t) == 0ull ? 1 : 0) + (ballot(t2.y > min_hit && t2.y < best_t) == 0ull ? 1 : 0));
         st.count(CT_RECT_RANGE_LANES, RT_LANES(t2.x > min_hit && t2.x < best_t) + RT_LANES(t2.y > min_hit && t2.y < best_t));
 #endif
 #pragma unroll
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     while (true) {
         uint32_t fetch_slot = 0xFFFFFFFFu;
         if (STAGE == 2) {
-            const unsigned long long asking = __ballot(need_sample && samples_left == 0);
+            const unsigned long long asking = ballot(need_sample && samples_left == 0);
             const uint32_t mine = wave_cursor + (uint32_t)__builtin_popcountll(asking & ((1ull << (threadIdx.x & 63u)) - 1ull));
             const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
             fetch_slot = ((gid >> 6) + (mine >> 6) * waves) * 64u + (mine & 63u);
@@ -925,10 +929,10 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
             }
         }
         st.mark(ST_START);
-        const unsigned long long active = __ballot(in_path);
+        const unsigned long long active = ballot(in_path);
         if (active == 0ull) break;   // no lane of the wave has a ray left
         if (STAGE == 1 && (uint32_t)__builtin_popcountll(active) <= p.pool_threshold &&
-            __ballot(in_path && samples_left > p.pool_max_samples) == 0ull)
+            ballot(in_path && samples_left > p.pool_max_samples) == 0ull)
             break;   // hand the tail over: few lanes left, each with little left to do
 
         wave_rays += (uint32_t)__builtin_popcountll(active);   // every lane with a ray traces it in this iteration (main.cpp:278)
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         // All rays of the wave are primary rays?  (Not asked in STAGE 2, whose waves hold streams of many tiles in
         // the middle of their paths: without the all-primary copy of the rectangle loop that kernel keeps a wave
         // per SIMD more; computing the origin rows gives the bits the stored ones have.)
-        const bool camera_origin = STAGE != 2 && __ballot(in_path && bounce != 0) == 0ull;
+        const bool camera_origin = STAGE != 2 && ballot(in_path && bounce != 0) == 0ull;
         Closest c;
         st.count(CT_ITERATIONS, 1);
         st.count(CT_LANES_TRACING, RT_LANES(in_path));
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     bool pixel_pending = false;           // STAGE 1: some stream of the lane's pixel was handed over
     if (RMODE == RT_RNG_PIXEL && STAGE != 0) {
         // Finished streams leave their sum, unfinished ones (STAGE 1 only) their state.
-        const unsigned long long unfinished = __ballot(in_path);
+        const unsigned long long unfinished = ballot(in_path);
         uint32_t base = 0;
         if (unfinished) {
             const uint32_t leader = (uint32_t)__builtin_ctzll(unfinished);
