@@ -138,6 +138,50 @@ uint32_t workgroup_threads(const rt_context* ctx) {
     return threads;
 }
 
+// Film constants of a render (main.cpp:350-368), and the margins of the primary-ray cull.
+void film_and_cull_constants(const rt_camera& c, uint32_t width, uint32_t height, bool cull, rt::KernelParams& k) {
+    // Film constants (main.cpp:350-368), rounded operation by operation.
+    float aspect = (float)(int32_t)width / (float)(int32_t)height;
+    float film_distance = 1.0f;
+    for (int i = 0; i < 3; ++i) {
+        k.cam_pos[i] = c.position[i];
+        k.cam_x[i] = c.x_axis[i];
+        k.cam_y[i] = c.y_axis[i];
+        k.film_center[i] = c.position[i] - c.z_axis[i] * film_distance;
+    }
+    float film_w = 1.0f * aspect, film_h = 1.0f;
+    k.half_w = film_w * 0.5f;
+    k.half_h = film_h * 0.5f;
+    k.pixel_w = 0.5f / (float)(int32_t)width;
+    k.pixel_h = 0.5f / (float)(int32_t)height;
+
+    // Primary-ray cull (rt_kernels.hpp, primary_pair_mask): a wave decides once which rectangles the primary rays
+    // of its pixel tile can reach, from the tile's patch of the film widened by this margin on every side, in
+    // film-plane units (one pixel is 1 / height wide in them).  The margin is one pixel plus a bound on how far
+    // the kernel's rounded ray set-up (film position, direction, normalisation: about a dozen operations on
+    // values of the camera position's magnitude) can move a ray on the film plane.  That bound reads the ray's
+    // error through the camera axes, so the cull is used only with axes that are orthonormal to 1e-3.
+    k.cull_margin = 0.0f;
+    if (cull) {
+        const float* axes[3] = {c.x_axis, c.y_axis, c.z_axis};
+        bool orthonormal = true;
+        double reach = 4.0;
+        for (int i = 0; i < 3; ++i) {
+            reach = std::fmax(reach, 4.0 + std::fabs((double)c.position[i]));
+            for (int j = i; j < 3; ++j) {
+                const double g = (double)axes[i][0] * axes[j][0] + (double)axes[i][1] * axes[j][1] + (double)axes[i][2] * axes[j][2];
+                orthonormal = orthonormal && std::fabs(g - (i == j ? 1.0 : 0.0)) <= 1.0e-3;
+            }
+        }
+        if (orthonormal) {
+            k.cull_margin = (float)(1.0 / (double)height + 0x1.0p-20 * reach);
+            // no primary direction D0 + a camX + b camY is longer than this (|a| <= half_w (1 + pixel_w) + margin, same for b)
+            k.cull_reach = (float)(1.002 * (1.0 + ((double)k.half_w * (1.0 + k.pixel_w) + k.cull_margin) +
+                                            ((double)k.half_h * (1.0 + k.pixel_h) + k.cull_margin)));
+        }
+    }
+}
+
 // `max_pool_entries` (0 = no limit) caps the pool of handed-over streams: the hand-over threshold is lowered
 // until waves * threshold entries fit, and with no room at all the render is planned as a single launch.
 rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* out, uint64_t max_pool_entries = 0) {
@@ -236,47 +280,7 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
         k.pool_capacity = (uint32_t)capacity;
     }
 
-    // Film constants (main.cpp:350-368), rounded operation by operation.
-    const rt_camera& c = ctx->camera;
-    float aspect = (float)(int32_t)p->width / (float)(int32_t)p->height;
-    float film_distance = 1.0f;
-    for (int i = 0; i < 3; ++i) {
-        k.cam_pos[i] = c.position[i];
-        k.cam_x[i] = c.x_axis[i];
-        k.cam_y[i] = c.y_axis[i];
-        k.film_center[i] = c.position[i] - c.z_axis[i] * film_distance;
-    }
-    float film_w = 1.0f * aspect, film_h = 1.0f;
-    k.half_w = film_w * 0.5f;
-    k.half_h = film_h * 0.5f;
-    k.pixel_w = 0.5f / (float)(int32_t)p->width;
-    k.pixel_h = 0.5f / (float)(int32_t)p->height;
-
-    // Primary-ray cull (rt_kernels.hpp, primary_pair_mask): a wave decides once which rectangles the primary rays
-    // of its pixel tile can reach, from the tile's patch of the film widened by this margin on every side, in
-    // film-plane units (one pixel is 1 / height wide in them).  The margin is one pixel plus a bound on how far
-    // the kernel's rounded ray set-up (film position, direction, normalisation: about a dozen operations on
-    // values of the camera position's magnitude) can move a ray on the film plane.  That bound reads the ray's
-    // error through the camera axes, so the cull is used only with axes that are orthonormal to 1e-3.
-    k.cull_margin = 0.0f;
-    if (p->rng_mode == RT_RNG_PIXEL && !(p->flags & RT_FLAG_NO_PRIMARY_CULL)) {
-        const float* axes[3] = {c.x_axis, c.y_axis, c.z_axis};
-        bool orthonormal = true;
-        double reach = 4.0;
-        for (int i = 0; i < 3; ++i) {
-            reach = std::fmax(reach, 4.0 + std::fabs((double)c.position[i]));
-            for (int j = i; j < 3; ++j) {
-                const double g = (double)axes[i][0] * axes[j][0] + (double)axes[i][1] * axes[j][1] + (double)axes[i][2] * axes[j][2];
-                orthonormal = orthonormal && std::fabs(g - (i == j ? 1.0 : 0.0)) <= 1.0e-3;
-            }
-        }
-        if (orthonormal) {
-            k.cull_margin = (float)(1.0 / (double)p->height + 0x1.0p-20 * reach);
-            // no primary direction D0 + a camX + b camY is longer than this (|a| <= half_w (1 + pixel_w) + margin, same for b)
-            k.cull_reach = (float)(1.002 * (1.0 + ((double)k.half_w * (1.0 + k.pixel_w) + k.cull_margin) +
-                                            ((double)k.half_h * (1.0 + k.pixel_h) + k.cull_margin)));
-        }
-    }
+    film_and_cull_constants(ctx->camera, p->width, p->height, p->rng_mode == RT_RNG_PIXEL && !(p->flags & RT_FLAG_NO_PRIMARY_CULL), k);
     return RT_OK;
 }
 
@@ -969,6 +973,33 @@ rt_status rt_render_multi(rt_context* const* contexts, uint32_t context_count, c
 rt_status rt_resolve(rt_context* ctx, const float* radiance_sum, uint64_t pixel_count, uint32_t total_samples,
                      uint32_t* pixels, float* radiance_mean) {
     return guarded([&] { return resolve_impl(ctx, radiance_sum, pixel_count, total_samples, pixels, radiance_mean); });
+}
+
+// Test hook (not declared in include/rt_hip.h, runs on the host, needs no GPU): which rectangles of `world` would a
+// wave whose pixels are [x0, x1] x [row0, row1] of a width x height image keep for its primary rays?  The scene
+// image, the cull table, the film constants, the margins and the evaluation are the ones the render uses
+// (pack_scene_image, film_and_cull_constants, cull_box, cull_keeps); reachable[i] answers for rectangle i of the
+// caller's array.  intersect_mode selects the image (their stored camera rows differ in rounding).
+rt_status rt_debug_cull_reachable(const rt_world* world, uint32_t width, uint32_t height, uint32_t intersect_mode, uint32_t x0,
+                                  uint32_t x1, uint32_t row0, uint32_t row1, uint8_t* reachable) {
+    return guarded([&]() -> rt_status {
+        if (!world || !world->camera || !reachable || width == 0 || height == 0 || x1 < x0 || row1 < row0 || x1 >= width || row1 >= height)
+            return RT_ERR_INVALID_ARGUMENT;
+        const uint32_t lanes = intersect_mode == RT_INTERSECT_WIDE8 ? 8u : intersect_mode == RT_INTERSECT_WIDE4 ? 4u : 0u;
+        const std::vector<uint32_t> image = rt::pack_scene_image(*world, lanes);
+        rt::KernelParams k;
+        std::memset(&k, 0, sizeof k);
+        film_and_cull_constants(*world->camera, width, height, true, k);
+        const std::vector<uint32_t> order = lanes ? rt::wide_order(world->rectangle_count, lanes) : std::vector<uint32_t>();
+        const rt::CullBox box = rt::cull_box(width, height, k.pixel_w, k.pixel_h, k.half_w, k.half_h, k.cull_margin, x0, x1, row0, row1);
+        for (uint32_t slot = 0; slot < world->rectangle_count; ++slot) {
+            double rec[rt::CULL_DOUBLES];
+            std::memcpy(rec, &image[image[rt::H_OFF_CULL] + 2u * rt::CULL_DOUBLES * slot], sizeof rec);
+            const bool keeps = k.cull_margin > 0.0f ? rt::cull_keeps(rec, box, (double)k.cull_reach) : true;
+            reachable[lanes ? order[slot] : slot] = keeps ? 1 : 0;
+        }
+        return RT_OK;
+    });
 }
 
 #ifdef RT_STAMPS

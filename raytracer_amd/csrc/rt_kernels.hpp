@@ -354,34 +354,11 @@ __device__ __forceinline__ unsigned long long primary_pair_mask(const double* __
                                                                 const KernelParams& p, uint32_t x0, uint32_t x1, uint32_t row0,
                                                                 uint32_t row1) {
     const uint32_t lane = threadIdx.x & 63u, n_pairs = sv.n_rects / 2u;
-    // The box: film coordinates as main.cpp:375-388 forms them (float; their rounding is four orders of magnitude
-    // below the widening), jitter, margin.
-    const float fx0 = ((float)(int32_t)x0 / (float)(int32_t)p.width) * 2.0f - 1.0f, fx1 = ((float)(int32_t)x1 / (float)(int32_t)p.width) * 2.0f - 1.0f;
-    const float fy0 = ((float)(int32_t)row0 / (float)(int32_t)p.height) * -2.0f + 1.0f, fy1 = ((float)(int32_t)row1 / (float)(int32_t)p.height) * -2.0f + 1.0f;   // fy1 <= fy0
-    const double a_lo = (double)((fx0 - p.pixel_w) * p.half_w - p.cull_margin), a_hi = (double)((fx1 + p.pixel_w) * p.half_w + p.cull_margin);
-    const double b_lo = (double)((fy1 - p.pixel_h) * p.half_h - p.cull_margin), b_hi = (double)((fy0 + p.pixel_h) * p.half_h + p.cull_margin);
-    // extremes of alpha + beta a + gamma b over the box
-    auto lowest = [&](const double* f) { return f[0] + (f[1] > 0.0 ? f[1] * a_lo : f[1] * a_hi) + (f[2] > 0.0 ? f[2] * b_lo : f[2] * b_hi); };
-    auto highest = [&](const double* f) { return f[0] + (f[1] > 0.0 ? f[1] * a_hi : f[1] * a_lo) + (f[2] > 0.0 ? f[2] * b_hi : f[2] * b_lo); };
+    const CullBox box = cull_box(p.width, p.height, p.pixel_w, p.pixel_h, p.half_w, p.half_h, p.cull_margin, x0, x1, row0, row1);
     bool keep = false;
 #pragma unroll 1
-    for (uint32_t which = 0; which < (lane < n_pairs ? 2u : 0u); ++which) {
-        const double* rec = cull_table + (size_t)CULL_DOUBLES * (2u * lane + which);
-        const double grazing = rec[CULL_GRAZING];
-        if (grazing < 0.0) continue;                        // a rectangle that nothing can hit (zero padding)
-        // d'z = r2 . D keeps one sign over the patch and no ray is within 1e-3 (as a cosine) of parallel to the plane?
-        const double limit = grazing * (double)p.cull_reach;
-        const bool all_pos = lowest(rec + CULL_W) >= limit, all_neg = highest(rec + CULL_W) <= -limit;
-        if (!(all_pos || all_neg)) { keep = true; continue; }                      // not decided here
-        const double oz = rec[CULL_OZ];
-        if (oz == 0.0 || (oz > 0.0) == all_pos) continue;                        // t = -o'z / d'z <= 0 for every ray
-        // In front: all rays pass the plane beyond one edge of the square, margin included?
-        const bool right = all_pos ? lowest(rec + CULL_RIGHT) > 0.0 : highest(rec + CULL_RIGHT) < 0.0;
-        const bool left = all_pos ? highest(rec + CULL_LEFT) < 0.0 : lowest(rec + CULL_LEFT) > 0.0;
-        const bool above = all_pos ? lowest(rec + CULL_ABOVE) > 0.0 : highest(rec + CULL_ABOVE) < 0.0;
-        const bool below = all_pos ? highest(rec + CULL_BELOW) < 0.0 : lowest(rec + CULL_BELOW) > 0.0;
-        if (!(right || left || above || below)) keep = true;
-    }
+    for (uint32_t which = 0; which < (lane < n_pairs ? 2u : 0u); ++which)
+        keep = keep || cull_keeps(cull_table + (size_t)CULL_DOUBLES * (2u * lane + which), box, (double)p.cull_reach);
     return ballot(keep);
 }
 

@@ -77,6 +77,53 @@ inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 //   OZ     o'z.
 enum : uint32_t { CULL_W = 0, CULL_RIGHT = 3, CULL_LEFT = 6, CULL_ABOVE = 9, CULL_BELOW = 12, CULL_GRAZING = 15, CULL_OZ = 16, CULL_DOUBLES = 18 };
 
+#if defined(__HIPCC__)
+#define RT_HOST_DEVICE __host__ __device__
+#else
+#define RT_HOST_DEVICE
+#endif
+
+// The patch of the film through which the primary rays of the pixels [x0, x1] x [row0, row1] (global rows) leave the
+// camera, as a box in film-plane coordinates (a along camX, b along camY): film coordinates as main.cpp:375-388
+// forms them (in float, like the render: their rounding is four orders of magnitude below the widening), the
+// quarter-pixel jitter, and the margin.
+struct CullBox { double a_lo, a_hi, b_lo, b_hi; };
+RT_HOST_DEVICE inline CullBox cull_box(uint32_t width, uint32_t height, float pixel_w, float pixel_h, float half_w, float half_h,
+                                       float margin, uint32_t x0, uint32_t x1, uint32_t row0, uint32_t row1) {
+    const float fx0 = ((float)(int32_t)x0 / (float)(int32_t)width) * 2.0f - 1.0f, fx1 = ((float)(int32_t)x1 / (float)(int32_t)width) * 2.0f - 1.0f;
+    const float fy0 = ((float)(int32_t)row0 / (float)(int32_t)height) * -2.0f + 1.0f, fy1 = ((float)(int32_t)row1 / (float)(int32_t)height) * -2.0f + 1.0f;   // fy1 <= fy0
+    CullBox box;
+    box.a_lo = (double)((fx0 - pixel_w) * half_w - margin); box.a_hi = (double)((fx1 + pixel_w) * half_w + margin);
+    box.b_lo = (double)((fy1 - pixel_h) * half_h - margin); box.b_hi = (double)((fy0 + pixel_h) * half_h + margin);
+    return box;
+}
+
+// Must the rectangle of this cull record be tested for the primary rays of the box?  false only if no such ray can
+// pass the rectangle test (see the record's description above).  A linear function takes its extremes over a box at
+// the corners picked by the signs of its two slopes.
+RT_HOST_DEVICE inline bool cull_keeps(const double* rec, const CullBox& box, double reach) {
+    auto lowest = [&](const double* f) {
+        return f[0] + (f[1] > 0.0 ? f[1] * box.a_lo : f[1] * box.a_hi) + (f[2] > 0.0 ? f[2] * box.b_lo : f[2] * box.b_hi);
+    };
+    auto highest = [&](const double* f) {
+        return f[0] + (f[1] > 0.0 ? f[1] * box.a_hi : f[1] * box.a_lo) + (f[2] > 0.0 ? f[2] * box.b_hi : f[2] * box.b_lo);
+    };
+    const double grazing = rec[CULL_GRAZING];
+    if (grazing < 0.0) return false;                       // a rectangle that nothing can hit (zero padding)
+    // d'z = r2 . D keeps one sign over the patch and no ray is within 1e-3 (as a cosine) of parallel to the plane?
+    const double limit = grazing * reach;
+    const bool all_pos = lowest(rec + CULL_W) >= limit, all_neg = highest(rec + CULL_W) <= -limit;
+    if (!(all_pos || all_neg)) return true;                // not decided here
+    const double oz = rec[CULL_OZ];
+    if (oz == 0.0 || (oz > 0.0) == all_pos) return false;  // t = -o'z / d'z <= 0 for every ray
+    // In front: do all rays pass the plane beyond one edge of the square, margin included?
+    const bool right = all_pos ? lowest(rec + CULL_RIGHT) > 0.0 : highest(rec + CULL_RIGHT) < 0.0;
+    const bool left = all_pos ? highest(rec + CULL_LEFT) < 0.0 : lowest(rec + CULL_LEFT) > 0.0;
+    const bool above = all_pos ? lowest(rec + CULL_ABOVE) > 0.0 : highest(rec + CULL_ABOVE) < 0.0;
+    const bool below = all_pos ? highest(rec + CULL_BELOW) < 0.0 : lowest(rec + CULL_BELOW) > 0.0;
+    return !(right || left || above || below);
+}
+
 // m: the rectangle's inverse transform; o: the stored camera-origin transform (o'x, o'y, o'z).
 inline void cull_record(const float (*m)[4], const float o[3], const rt_camera& cam, double* rec) {
     const double ox = o[0], oy = o[1], oz = o[2];
