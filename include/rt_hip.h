@@ -130,7 +130,12 @@ enum {  /* rt_render_params.flags */
     /* RT_RNG_PIXEL renders skip, in iterations whose rays are all primary rays, the rectangles that no primary
      * ray of the wave's pixel tile can reach (decided once per wave, conservatively: same pixels, same ray
      * count).  This flag switches the skip off, for A/B measurements and tests. */
-    RT_FLAG_NO_PRIMARY_CULL = 16u
+    RT_FLAG_NO_PRIMARY_CULL = 16u,
+    /* Rectangles whose inverse transform holds the exact zeros of a rotation about the x or the y axis are
+     * tested without the multiply-adds of those entries (same pixels, same ray count: a term with a zero factor
+     * changes nothing a comparison can see).  This flag makes every rectangle use the full 3x4 transform, for A/B
+     * measurements and tests. */
+    RT_FLAG_DENSE_TRANSFORMS = 32u
 };
 
 typedef struct rt_render_params {

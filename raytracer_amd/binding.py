@@ -21,7 +21,7 @@ LIB_PATH = pathlib.Path(os.environ.get("RT_HIP_LIBRARY", _PKG / "librt_hip.so"))
 RT_OK = 0
 RNG_ROW_SERIAL, RNG_PIXEL = 0, 1
 INTERSECT_WIDE8, INTERSECT_SCALAR, INTERSECT_WIDE4 = 0, 1, 2
-FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL, FLAG_COMPACT_TAILS, FLAG_ACCUMULATE, FLAG_NO_PRIMARY_CULL = 1, 2, 4, 8, 16
+FLAG_OUTPUT_SUM, FLAG_TIME_KERNEL, FLAG_COMPACT_TAILS, FLAG_ACCUMULATE, FLAG_NO_PRIMARY_CULL, FLAG_DENSE_TRANSFORMS = 1, 2, 4, 8, 16, 32
 
 # Every symbol include/rt_hip.h declares.
 EXPORTS = (

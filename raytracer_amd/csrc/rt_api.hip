@@ -42,6 +42,7 @@ struct rt_context {
     bool mixed = false;             // spheres and rectangles both present
     rt_camera camera{};
     uint32_t image_words[3] = {0, 0, 0};
+    unsigned long long rect_about_y[3] = {0, 0, 0}, rect_about_x[3] = {0, 0, 0};   // the images' sparsity masks (rt_layout.hpp)
     uint32_t lds_words = 0;                 // part of the image each workgroup stages in LDS (same for both images)
     uint32_t sphere_count = 0, sphere_offset = 0, sphere_tag_offset = 0;
     uint4* d_image[3] = {nullptr, nullptr, nullptr};   // indexed by RT_INTERSECT_*
@@ -227,6 +228,8 @@ rt_status validate_and_plan(rt_context* ctx, const rt_render_params* p, Launch* 
     k.sphere_count = ctx->sphere_count;
     k.sphere_offset = ctx->sphere_offset;
     k.sphere_tag_offset = ctx->sphere_tag_offset;
+    k.rect_about_y = (p->flags & RT_FLAG_DENSE_TRANSFORMS) ? 0ull : ctx->rect_about_y[out->imode];
+    k.rect_about_x = (p->flags & RT_FLAG_DENSE_TRANSFORMS) ? 0ull : ctx->rect_about_x[out->imode];
 
     uint64_t lanes;
     if (p->rng_mode == RT_RNG_ROW_SERIAL) {
@@ -774,6 +777,8 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
         if (ctx->d_image[i]) (void)hipFree(ctx->d_image[i]);
         ctx->d_image[i] = fresh[i];
         ctx->image_words[i] = (uint32_t)images[i].size();
+        ctx->rect_about_y[i] = images[i][rt::H_RECT_ABOUT_Y] | ((unsigned long long)images[i][rt::H_RECT_ABOUT_Y + 1] << 32);
+        ctx->rect_about_x[i] = images[i][rt::H_RECT_ABOUT_X] | ((unsigned long long)images[i][rt::H_RECT_ABOUT_X + 1] << 32);
     }
     ctx->camera = *w->camera;
     ctx->lds_words = images[0][rt::H_LDS_WORDS];
@@ -997,6 +1002,23 @@ rt_status rt_debug_cull_reachable(const rt_world* world, uint32_t width, uint32_
             std::memcpy(rec, &image[image[rt::H_OFF_CULL] + 2u * rt::CULL_DOUBLES * slot], sizeof rec);
             const bool keeps = k.cull_margin > 0.0f ? rt::cull_keeps(rec, box, (double)k.cull_reach) : true;
             reachable[lanes ? order[slot] : slot] = keeps ? 1 : 0;
+        }
+        return RT_OK;
+    });
+}
+
+// Test hook (host only, no GPU): the sparsity class (rt_layout.hpp, rect_sparsity_class) the scene image of
+// `intersect_mode` records for rectangle i of the caller's array; 0 for rectangles beyond the first 64 slots.
+rt_status rt_debug_rect_classes(const rt_world* world, uint32_t intersect_mode, uint8_t* classes) {
+    return guarded([&]() -> rt_status {
+        if (!world || !world->camera || !classes) return RT_ERR_INVALID_ARGUMENT;
+        const uint32_t lanes = intersect_mode == RT_INTERSECT_WIDE8 ? 8u : intersect_mode == RT_INTERSECT_WIDE4 ? 4u : 0u;
+        const std::vector<uint32_t> image = rt::pack_scene_image(*world, lanes);
+        const std::vector<uint32_t> order = lanes ? rt::wide_order(world->rectangle_count, lanes) : std::vector<uint32_t>();
+        for (uint32_t slot = 0; slot < world->rectangle_count; ++slot) {
+            const bool y = slot < 64u && ((image[rt::H_RECT_ABOUT_Y + slot / 32u] >> (slot % 32u)) & 1u);
+            const bool x = slot < 64u && ((image[rt::H_RECT_ABOUT_X + slot / 32u] >> (slot % 32u)) & 1u);
+            classes[lanes ? order[slot] : slot] = y ? 1 : x ? 2 : 0;
         }
         return RT_OK;
     });

@@ -49,6 +49,7 @@ struct KernelParams {
     float half_w, half_h, pixel_w, pixel_h;
     float cull_margin;      // PIXEL: > 0 enables the per-wave primary-ray cull; film-plane widening of a tile's footprint (see primary_pair_mask)
     float cull_reach;       // upper bound on the length of an un-normalised primary direction (film at distance 1)
+    unsigned long long rect_about_y, rect_about_x;   // rectangle slots (bit k: slot k < 64) by sparsity class, see rect_sparsity_class
 };
 
 // Device workspace of the tail compaction: per-stream sums, the pool of unfinished streams and its fill count.
@@ -212,6 +213,56 @@ __device__ __forceinline__ F2 div2(F2 a, F2 b) {
     return fma2(r, y, q);
 }
 
+// One such quotient.
+__device__ __forceinline__ float div1(float a, float b) {
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// A row (m0 m1 m2 m3) of a rectangle's inverse transform applied to a point v (w = 1), in the arithmetic of the
+// mode: WIDE8 is DotProduct(LaneVector4), fma(x,x', fma(y,y', fma(z,z', w*w'))) with w*1 exact; the others are
+// DotProduct(Vector4), x*x' + y*y' + z*z' + w*w' from left to right (math_vector.h:341-343).  Zk (compile time):
+// mk is an exact zero and its term is left out - the term is a zero of either sign (v is finite), and adding it
+// would change at most the sign of a sum that is itself zero.
+template <int IMODE, bool Z0, bool Z1, bool Z2>
+__device__ __forceinline__ float affine_row(float m0, float m1, float m2, float m3, V3 v) {
+    if (IMODE == RT_INTERSECT_WIDE8) {
+        float acc = m3;
+        if (!Z2) acc = __builtin_fmaf(m2, v.z, acc);
+        if (!Z1) acc = __builtin_fmaf(m1, v.y, acc);
+        if (!Z0) acc = __builtin_fmaf(m0, v.x, acc);
+        return acc;
+    }
+    float acc = 0.0f;
+    bool have = false;
+    if (!Z0) { acc = m0 * v.x; have = true; }
+    if (!Z1) { acc = have ? acc + m1 * v.y : m1 * v.y; have = true; }
+    if (!Z2) { acc = have ? acc + m2 * v.z : m2 * v.z; have = true; }
+    return have ? acc + m3 : m3;
+}
+// The same row applied to a direction (w = 0: the reference adds a zero there, which is left out as well).
+template <int IMODE, bool Z0, bool Z1, bool Z2>
+__device__ __forceinline__ float linear_row(float m0, float m1, float m2, V3 v) {
+    float acc = 0.0f;
+    bool have = false;
+    if (IMODE == RT_INTERSECT_WIDE8) {
+        if (!Z2) { acc = m2 * v.z; have = true; }
+        if (!Z1) { acc = have ? __builtin_fmaf(m1, v.y, acc) : m1 * v.y; have = true; }
+        if (!Z0) { acc = have ? __builtin_fmaf(m0, v.x, acc) : m0 * v.x; have = true; }
+        return acc;
+    }
+    if (!Z0) { acc = m0 * v.x; have = true; }
+    if (!Z1) { acc = have ? acc + m1 * v.y : m1 * v.y; have = true; }
+    if (!Z2) { acc = have ? acc + m2 * v.z : m2 * v.z; have = true; }
+    return acc;
+}
+
 // math_util.h:32-50.  (float)U32Max is 2^32, so the division is an exact scaling.
 __device__ __forceinline__ uint32_t xorshift32(uint32_t& s) {
     uint32_t x = s;
@@ -276,6 +327,7 @@ struct SceneView {
     const uint32_t* gtags;    // sphere tags (material | lane << 24) in the global image
     uint32_t n_planes, n_spheres, n_rects;
     uint32_t off_planes, off_rects, off_mats;
+    unsigned long long rect_about_y, rect_about_x;   // KernelParams' masks (scalar registers)
 };
 
 // World intersection.  best_id: 0 = miss, 1+i plane i, 1+np+k sphere slot k,
@@ -533,11 +585,10 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
 
     st.mark(ST_SPHERE_TERMS);
     // Rectangles (main.cpp:96-129 / 212-239): ray into the rectangle's frame, hit the
-    // z = 0 plane, test against the unit square.  Two rectangles (A, B) per step (the scene image stores
-    // them interleaved: rows 0 and 1 of A, of B, then the two row-2 vectors), which gives the scheduler
-    // twelve independent multiply-add chains and two divisions to interleave.
-    const F2 ox2 = splat(o.x), oy2 = splat(o.y), oz2 = splat(o.z);
-    const F2 dx2 = splat(d.x), dy2 = splat(d.y), dz2 = splat(d.z);
+    // z = 0 plane, test against the unit square.  The scene image stores them in pairs (rows 0 and 1 of A, of B,
+    // then the two row-2 vectors), and a step of the loop tests the two rectangles of a pair, each by the copy of
+    // the test that matches the exact zeros of its matrix (rect_sparsity_class; a scalar branch on the host's
+    // masks): a rectangle turned about one axis costs 10 multiply-adds for the transforms instead of 18.
     const uint32_t rect_base = 1 + sv.n_planes + sv.n_spheres;
     const uint32_t n_pairs = (PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u;
     // One pair.  CAMERA is a compile-time copy of camera_origin: the loop exists twice, so that neither copy
@@ -545,65 +596,68 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     auto test_pair = [&](uint32_t pair, auto camera_tag) {
         constexpr bool CAMERA = decltype(camera_tag)::value;
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
-        const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3], z01 = rec[4], z23 = rec[5];
-        F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
-        if (CAMERA) {
-            const float4 c01 = rec[8], c2 = rec[9];
-            a_lo = f2(c01.x, c01.y); b_lo = f2(c01.z, c01.w); z_lo = f2(c2.x, c2.y);
-        } else if (IMODE == RT_INTERSECT_WIDE8) {
-            // DotProduct(LaneVector4): fma(x,x', fma(y,y', fma(z,z', w*w'))) with w' = 1 for the
-            // origin (w*1 is exact).
-            a_lo = fma2(f2(a01.x, a01.y), ox2, fma2(f2(a01.z, a01.w), oy2, fma2(f2(a23.x, a23.y), oz2, f2(a23.z, a23.w))));
-            b_lo = fma2(f2(b01.x, b01.y), ox2, fma2(f2(b01.z, b01.w), oy2, fma2(f2(b23.x, b23.y), oz2, f2(b23.z, b23.w))));
-            z_lo = fma2(f2(z01.x, z01.y), ox2, fma2(f2(z01.z, z01.w), oy2, fma2(f2(z23.x, z23.y), oz2, f2(z23.z, z23.w))));
-        } else {
-            // DotProduct(Vector4): x*x' + y*y' + z*z' + w*w', left to right (math_vector.h:341-343).
-            a_lo = f2(a01.x, a01.y) * ox2 + f2(a01.z, a01.w) * oy2 + f2(a23.x, a23.y) * oz2 + f2(a23.z, a23.w);
-            b_lo = f2(b01.x, b01.y) * ox2 + f2(b01.z, b01.w) * oy2 + f2(b23.x, b23.y) * oz2 + f2(b23.z, b23.w);
-            z_lo = f2(z01.x, z01.y) * ox2 + f2(z01.z, z01.w) * oy2 + f2(z23.x, z23.y) * oz2 + f2(z23.z, z23.w);
-        }
-        if (IMODE == RT_INTERSECT_WIDE8) {
-            // w' = 0 for the direction (adds a zero: only the sign of an exact zero could differ,
-            // which no comparison below can see).
-            a_ld = fma2(f2(a01.x, a01.y), dx2, fma2(f2(a01.z, a01.w), dy2, f2(a23.x, a23.y) * dz2));
-            b_ld = fma2(f2(b01.x, b01.y), dx2, fma2(f2(b01.z, b01.w), dy2, f2(b23.x, b23.y) * dz2));
-            z_ld = fma2(f2(z01.x, z01.y), dx2, fma2(f2(z01.z, z01.w), dy2, f2(z23.x, z23.y) * dz2));
-        } else {
-            a_ld = f2(a01.x, a01.y) * dx2 + f2(a01.z, a01.w) * dy2 + f2(a23.x, a23.y) * dz2;
-            b_ld = f2(b01.x, b01.y) * dx2 + f2(b01.z, b01.w) * dy2 + f2(b23.x, b23.y) * dz2;
-            z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
-        }
-        const F2 t2 = div2(-z_lo, z_ld);   // t = (-origin'.z) / direction'.z for A and B
+        // Row 2 of both rectangles (and the camera rows) are read once per pair.  Reading them per rectangle would
+        // free four registers and a wave per SIMD more would fit (61 instead of 65), but the two extra LDS reads per
+        // pair cost more than the eighth wave brings (16.55 against 16.29 ms on the Cornell bench).
+        const float4 z01 = rec[4], z23 = rec[5];
+        float4 c01 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c2 = c01;
+        if (CAMERA) { c01 = rec[8]; c2 = rec[9]; }
+        // sparsity classes of the pair's two slots: bit 0 = A, bit 1 = B
+        const uint32_t about_y = pair < 32u ? (uint32_t)(sv.rect_about_y >> (2u * pair)) & 3u : 0u;
+        const uint32_t about_x = pair < 32u ? (uint32_t)(sv.rect_about_x >> (2u * pair)) & 3u : 0u;
+        auto one = [&](auto which_tag) -> float {
+            constexpr int which = decltype(which_tag)::value;
+            const float4 r01 = rec[2 * which], r23 = rec[2 * which + 1];   // (m00 m10 m01 m11) (m02 m12 m03 m13)
+            const float m20 = which ? z01.y : z01.x, m21 = which ? z01.w : z01.z, m22 = which ? z23.y : z23.x, m23 = which ? z23.w : z23.z;
+            auto body = [&](auto sparsity_tag) -> float {
+                constexpr int S = decltype(sparsity_tag)::value;
+                constexpr bool Z01 = S != 0, Z10 = S != 0, Z12 = S == 1, Z21 = S == 1, Z02 = S == 2, Z20 = S == 2;
+                float lo_x, lo_y, lo_z;     // the origin in the rectangle's frame
+                if (CAMERA) {
+                    lo_x = which ? c01.z : c01.x; lo_y = which ? c01.w : c01.y; lo_z = which ? c2.y : c2.x;
+                } else {
+                    lo_x = affine_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, r23.z, o);
+                    lo_y = affine_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, r23.w, o);
+                    lo_z = affine_row<IMODE, Z20, Z21, false>(m20, m21, m22, m23, o);
+                }
+                const float ld_x = linear_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, d);
+                const float ld_y = linear_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, d);
+                const float ld_z = linear_row<IMODE, Z20, Z21, false>(m20, m21, m22, d);
+                const float t = div1(-lo_z, ld_z);   // t = (-origin'.z) / direction'.z
 #ifdef RT_STAMPS
-        // How often could a wave skip work here?  Pairs whose two planes lie behind every ray of the wave
-        // (t <= 0 on all lanes), and rectangles that no lane's t passes min_hit < t < closest so far.
-        st.count(CT_RECT_PAIRS, 1);
-        st.count(CT_RECT_PAIRS_BEHIND, ballot(t2.x > 0.0f || t2.y > 0.0f) == 0ull ? 1 : 0);
-        st.count(CT_RECTS_OUT_OF_RANGE, (ballot(t2.x > min_hit && t2.x < best_t) == 0ull ? 1 : 0) + (ballot(t2.y > min_hit && t2.y < best_t) == 0ull ? 1 : 0));
-        st.count(CT_RECT_RANGE_LANES, RT_LANES(t2.x > min_hit && t2.x < best_t) + RT_LANES(t2.y > min_hit && t2.y < best_t));
+                // rectangles that no lane's t passes min_hit < t < closest so far
+                st.count(CT_RECTS_OUT_OF_RANGE, ballot(t > min_hit && t < best_t) == 0ull ? 1 : 0);
+                st.count(CT_RECT_RANGE_LANES, RT_LANES(t > min_hit && t < best_t));
 #endif
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const F2 lo = which ? b_lo : a_lo, ld = which ? b_ld : a_ld;
-            const float t = which ? t2.y : t2.x;
-            const F2 h = lo + ld * splat(t);
-            if (!MIXED) {
-                update_closest_rect(h.x, h.y, t, min_hit, rect_base + 2 * pair + which, best_t, best_id);
-                continue;
-            }
-            bool closer = t < best_t;
-            if (MIXED) {
-                // A sphere and a rectangle at exactly the same t: the reference keeps the lower
-                // AVX lane, and within one lane the sphere, which it tested first.
-                uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
-                closer = closer || (t == best_t && lane < best_lane);
-            }
-            if (__builtin_fabsf(h.x) <= 1.0f && __builtin_fabsf(h.y) <= 1.0f && closer && t > min_hit) {
-                best_t = t;
-                best_id = rect_base + 2 * pair + which;
-                if (MIXED) best_lane = 0;
-            }
-        }
+                const float hx = lo_x + ld_x * t, hy = lo_y + ld_y * t;
+                if (!MIXED) {
+                    update_closest_rect(hx, hy, t, min_hit, rect_base + 2 * pair + which, best_t, best_id);
+                } else {
+                    // A sphere and a rectangle at exactly the same t: the reference keeps the lower
+                    // AVX lane, and within one lane the sphere, which it tested first.
+                    const uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
+                    const bool closer = t < best_t || (t == best_t && lane < best_lane);
+                    if (__builtin_fabsf(hx) <= 1.0f && __builtin_fabsf(hy) <= 1.0f && closer && t > min_hit) {
+                        best_t = t;
+                        best_id = rect_base + 2 * pair + which;
+                        best_lane = 0;
+                    }
+                }
+                return t;
+            };
+            if ((about_y >> which) & 1u) return body(std::integral_constant<int, 1>());
+            if ((about_x >> which) & 1u) return body(std::integral_constant<int, 2>());
+            return body(std::integral_constant<int, 0>());
+        };
+        const float t_a = one(std::integral_constant<int, 0>());
+        const float t_b = one(std::integral_constant<int, 1>());
+#ifdef RT_STAMPS
+        // pairs whose two planes lie behind every ray of the wave (t <= 0 on all lanes)
+        st.count(CT_RECT_PAIRS, 1);
+        st.count(CT_RECT_PAIRS_BEHIND, ballot(t_a > 0.0f || t_b > 0.0f) == 0ull ? 1 : 0);
+#else
+        (void)t_a; (void)t_b;
+#endif
     };
     if (camera_origin) {
         // All rays are primary rays: only the pairs one of them can hit (primary_pair_mask), in increasing order.
@@ -749,6 +803,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     sv.gtags = reinterpret_cast<const uint32_t*>(scene_image) + p.sphere_tag_offset;
     sv.off_planes = sv.u[H_OFF_PLANES];
     sv.off_rects = sv.u[H_OFF_RECTS]; sv.off_mats = sv.u[H_OFF_MATS];
+    sv.rect_about_y = p.rect_about_y; sv.rect_about_x = p.rect_about_x;
     if ((PRIMS & PRIMS_FEW) && sv.n_spheres) {
         // all records and tags into the wave's slice, once; LDS operations of a wave execute in order
         const uint32_t lane = threadIdx.x & 63u, k = min(lane, sv.n_spheres - 1u);

@@ -6,7 +6,7 @@
 // workgroup with a flat 16-byte copy; the sphere records stay in global memory, from where
 // every wave copies them, 64 at a time, into its own LDS slice (rt_kernels.hpp, intersect_world).
 //
-//   header   16 words  counts and section offsets (in words)
+//   header   16 words  counts and section offsets (in words); words 12-15: sparsity classes of the first 64 rectangle slots
 //   planes    8 words  nx ny nz d | material 0 0 0
 //   rects    40 words per PAIR of rectangles (A, B), the two handled side by side:
 //              A.r0x A.r1x A.r0y A.r1y | A.r0z A.r1z A.r0w A.r1w      rows 0,1 of A's inverse transform, interleaved
@@ -45,8 +45,28 @@ namespace rt {
 enum : uint32_t {
     H_NPLANES = 0, H_NSPHERES, H_NRECTS, H_NMATS,
     H_OFF_PLANES, H_OFF_SPHERES, H_OFF_SPHERE_TAGS, H_OFF_RECTS, H_OFF_MATS, H_TOTAL_WORDS, H_LDS_WORDS, H_OFF_CULL,
+    H_RECT_ABOUT_Y = 12, H_RECT_ABOUT_X = 14,   // two words each: bit k set = rectangle slot k (k < 64) has that sparsity
     H_WORDS = 16
 };
+
+// Sparsity classes of a rectangle's inverse transform.  Scenes are mostly built from rectangles that were
+// scaled, turned about ONE coordinate axis and moved, and their matrices then hold exact zeros:
+//   1, about y:  m01 = m10 = m12 = m21 = 0        2, about x:  m01 = m02 = m10 = m20 = 0        0: neither
+// The product of an exact zero and a finite coordinate is a zero, and adding a zero changes at most the sign of a
+// sum that is itself zero, which none of the rectangle test's comparisons can see: the kernel leaves such terms
+// out (rt_kernels.hpp, rectangle loop).  Precondition: the ray's origin and direction are finite (0 * inf would
+// be a NaN in the reference's full transform).  Hit points lie on the scene's surfaces, so this holds as long as
+// those are of ordinary size; a rectangle whose matrix has entries above 2^40 or a row shorter than 2^-40 (an
+// extent beyond 2^40) is left unclassified.
+inline uint32_t rect_sparsity_class(const float (*m)[4]) {
+    for (int row = 0; row < 3; ++row) {
+        const double n = (double)m[row][0] * m[row][0] + (double)m[row][1] * m[row][1] + (double)m[row][2] * m[row][2];
+        if (!(n >= 0x1.0p-80) || !(n <= 0x1.0p80) || !(std::fabs(m[row][3]) <= 0x1.0p40f)) return 0u;
+    }
+    if (m[0][1] == 0.0f && m[1][0] == 0.0f && m[1][2] == 0.0f && m[2][1] == 0.0f) return 1u;
+    if (m[0][1] == 0.0f && m[0][2] == 0.0f && m[1][0] == 0.0f && m[2][0] == 0.0f) return 2u;
+    return 0u;
+}
 
 constexpr uint32_t PLANE_WORDS = 8, SPHERE_WORDS = 4, RECT_PAIR_WORDS = 40, MAT_WORDS = 12;
 constexpr uint32_t WIDE_LANES = 8;        // simd.h:17; the SSE branch of simd.h:20-26 is 4 wide (RT_INTERSECT_WIDE4)
@@ -242,6 +262,10 @@ inline std::vector<uint32_t> pack_scene_image(const rt_world& w, uint32_t wide_l
             double rec[CULL_DOUBLES];
             cull_record(m, rows, *w.camera, rec);
             std::memcpy(&img[off_cull + 2u * CULL_DOUBLES * k], rec, sizeof rec);
+        }
+        if (k < 64u) {
+            const uint32_t cls = rect_sparsity_class(m);
+            if (cls) img[(cls == 1u ? H_RECT_ABOUT_Y : H_RECT_ABOUT_X) + k / 32u] |= 1u << (k % 32u);
         }
         uint32_t* tail = q + 24 + 4 * which;
         tail[0] = f2u(r.normal[0]); tail[1] = f2u(r.normal[1]); tail[2] = f2u(r.normal[2]);
