@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--lanes-per-pixel", type=int, default=0)
     ap.add_argument("--no-compact", action="store_true", help="single-launch render (no tail compaction)")
     ap.add_argument("--no-cull", action="store_true", help="switch the per-wave primary-ray cull off (A/B measurements)")
+    ap.add_argument("--dense-transforms", action="store_true", help="every rectangle through the full 3x4 transform, also those "
+                    "turned about one axis (A/B measurements)")
     ap.add_argument("--shard", choices=("samples", "rows"), default="samples")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="samples mode with N > 1: strong = a fixed total sample count split over the ranks (default), "
@@ -250,7 +252,8 @@ def main():
     info = ctx.device_info()
     ctx.upload_world(build_scene(*cfg["scene"]))
 
-    render_flags = (0 if args.no_compact else B.FLAG_COMPACT_TAILS) | (B.FLAG_NO_PRIMARY_CULL if args.no_cull else 0)
+    render_flags = (0 if args.no_compact else B.FLAG_COMPACT_TAILS) | (B.FLAG_NO_PRIMARY_CULL if args.no_cull else 0) | \
+                   (B.FLAG_DENSE_TRANSFORMS if args.dense_transforms else 0)
     base = B.default_params(W, H, spp, rng_mode=B.RNG_PIXEL, lanes_per_pixel=B_lanes, max_bounces=cfg["bounces"], flags=render_flags)
     total = args.steps + args.warmup
     radiance = gathered = sharded = None
@@ -415,7 +418,8 @@ def main():
                 profile = {}
         achieved = rank_rays_per_launch * flop_per_ray / (kernel_ms * 1e-3) / 1e12
         compacted = not args.no_compact and spp // B_lanes >= 8       # the library's rule (rt_api.hip)
-        key = f"{args.config}_{W}x{H}_{spp}spp" + ("" if compacted else "_single_launch") + ("_no_cull" if args.no_cull else "")
+        key = f"{args.config}_{W}x{H}_{spp}spp" + ("" if compacted else "_single_launch") + ("_no_cull" if args.no_cull else "") + \
+              ("_dense_transforms" if args.dense_transforms else "")
         traffic = profile.get(key) if world_size == 1 and B_lanes == cfg["lanes"] else None
         pairs = None
         cfile = ROOT / "profiles" / "cull_stats.json"
@@ -447,7 +451,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "rng_mode": "pixel", "lanes_per_pixel": B_lanes, "intersect_mode": "wide8",
-                       "compact_tails": compacted, "primary_ray_cull": not args.no_cull, "max_bounces": cfg["bounces"],
+                       "compact_tails": compacted, "primary_ray_cull": not args.no_cull,
+                       "zero_terms_of_turned_rectangles_left_out": not args.dense_transforms, "max_bounces": cfg["bounces"],
                        "spp_total": spp_total, "spp_per_gpu": spp, "rays_per_step": total_rays // max(args.steps, 1),
                        "shard": args.shard if distributed else None, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
                        "gather_overlapped_with_next_step": bool(overlap and not retried) if distributed and not rows_mode else None,

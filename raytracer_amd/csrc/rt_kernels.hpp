@@ -593,7 +593,8 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     const uint32_t n_pairs = (PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u;
     // One pair.  CAMERA is a compile-time copy of camera_origin: the loop exists twice, so that neither copy
     // branches on it.
-    auto test_pair = [&](uint32_t pair, auto camera_tag) {
+    // about_y / about_x: sparsity classes of the pair's two slots in bits 0 (A) and 1 (B); higher bits are ignored.
+    auto test_pair = [&](uint32_t pair, uint32_t about_y, uint32_t about_x, auto camera_tag) {
         constexpr bool CAMERA = decltype(camera_tag)::value;
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
         // Row 2 of both rectangles (and the camera rows) are read once per pair.  Reading them per rectangle would
@@ -602,14 +603,14 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         const float4 z01 = rec[4], z23 = rec[5];
         float4 c01 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c2 = c01;
         if (CAMERA) { c01 = rec[8]; c2 = rec[9]; }
-        // sparsity classes of the pair's two slots: bit 0 = A, bit 1 = B
-        const uint32_t about_y = pair < 32u ? (uint32_t)(sv.rect_about_y >> (2u * pair)) & 3u : 0u;
-        const uint32_t about_x = pair < 32u ? (uint32_t)(sv.rect_about_x >> (2u * pair)) & 3u : 0u;
         auto one = [&](auto which_tag) -> float {
             constexpr int which = decltype(which_tag)::value;
             const float4 r01 = rec[2 * which], r23 = rec[2 * which + 1];   // (m00 m10 m01 m11) (m02 m12 m03 m13)
             const float m20 = which ? z01.y : z01.x, m21 = which ? z01.w : z01.z, m22 = which ? z23.y : z23.x, m23 = which ? z23.w : z23.z;
-            auto body = [&](auto sparsity_tag) -> float {
+            // t and the hit point in the rectangle's frame, by the copy of the arithmetic for the matrix's class; the
+            // closest-hit update follows once, after the copies have joined.
+            float t, hx, hy;
+            auto body = [&](auto sparsity_tag) {
                 constexpr int S = decltype(sparsity_tag)::value;
                 constexpr bool Z01 = S != 0, Z10 = S != 0, Z12 = S == 1, Z21 = S == 1, Z02 = S == 2, Z20 = S == 2;
                 float lo_x, lo_y, lo_z;     // the origin in the rectangle's frame
@@ -623,31 +624,32 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                 const float ld_x = linear_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, d);
                 const float ld_y = linear_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, d);
                 const float ld_z = linear_row<IMODE, Z20, Z21, false>(m20, m21, m22, d);
-                const float t = div1(-lo_z, ld_z);   // t = (-origin'.z) / direction'.z
-#ifdef RT_STAMPS
-                // rectangles that no lane's t passes min_hit < t < closest so far
-                st.count(CT_RECTS_OUT_OF_RANGE, ballot(t > min_hit && t < best_t) == 0ull ? 1 : 0);
-                st.count(CT_RECT_RANGE_LANES, RT_LANES(t > min_hit && t < best_t));
-#endif
-                const float hx = lo_x + ld_x * t, hy = lo_y + ld_y * t;
-                if (!MIXED) {
-                    update_closest_rect(hx, hy, t, min_hit, rect_base + 2 * pair + which, best_t, best_id);
-                } else {
-                    // A sphere and a rectangle at exactly the same t: the reference keeps the lower
-                    // AVX lane, and within one lane the sphere, which it tested first.
-                    const uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
-                    const bool closer = t < best_t || (t == best_t && lane < best_lane);
-                    if (__builtin_fabsf(hx) <= 1.0f && __builtin_fabsf(hy) <= 1.0f && closer && t > min_hit) {
-                        best_t = t;
-                        best_id = rect_base + 2 * pair + which;
-                        best_lane = 0;
-                    }
-                }
-                return t;
+                t = div1(-lo_z, ld_z);   // t = (-origin'.z) / direction'.z
+                hx = lo_x + ld_x * t;
+                hy = lo_y + ld_y * t;
             };
-            if ((about_y >> which) & 1u) return body(std::integral_constant<int, 1>());
-            if ((about_x >> which) & 1u) return body(std::integral_constant<int, 2>());
-            return body(std::integral_constant<int, 0>());
+            if ((about_y >> which) & 1u) body(std::integral_constant<int, 1>());
+            else if ((about_x >> which) & 1u) body(std::integral_constant<int, 2>());
+            else body(std::integral_constant<int, 0>());
+#ifdef RT_STAMPS
+            // rectangles that no lane's t passes min_hit < t < closest so far
+            st.count(CT_RECTS_OUT_OF_RANGE, ballot(t > min_hit && t < best_t) == 0ull ? 1 : 0);
+            st.count(CT_RECT_RANGE_LANES, RT_LANES(t > min_hit && t < best_t));
+#endif
+            if (!MIXED) {
+                update_closest_rect(hx, hy, t, min_hit, rect_base + 2 * pair + which, best_t, best_id);
+            } else {
+                // A sphere and a rectangle at exactly the same t: the reference keeps the lower
+                // AVX lane, and within one lane the sphere, which it tested first.
+                const uint32_t lane = sv.u[sv.off_rects + RECT_PAIR_WORDS * pair + 24 + 4 * which + 3] >> TAG_LANE_SHIFT;
+                const bool closer = t < best_t || (t == best_t && lane < best_lane);
+                if (__builtin_fabsf(hx) <= 1.0f && __builtin_fabsf(hy) <= 1.0f && closer && t > min_hit) {
+                    best_t = t;
+                    best_id = rect_base + 2 * pair + which;
+                    best_lane = 0;
+                }
+            }
+            return t;
         };
         const float t_a = one(std::integral_constant<int, 0>());
         const float t_b = one(std::integral_constant<int, 1>());
@@ -667,7 +669,8 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         // (one loop for the masked pairs and for those beyond the mask: one copy of the body)
         uint32_t pair = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
         while (pair < n_pairs) {
-            test_pair(pair, std::true_type());
+            test_pair(pair, pair < 32u ? (uint32_t)(sv.rect_about_y >> (2u * pair)) : 0u,
+                      pair < 32u ? (uint32_t)(sv.rect_about_x >> (2u * pair)) : 0u, std::true_type());
             if (pair < 64u) {
                 todo &= todo - 1ull;
                 pair = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
@@ -677,7 +680,10 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
         }
     } else {
         st.count(CT_RECT_PAIR_RAYS, RT_LANES(active) * n_pairs);
-        for (uint32_t pair = 0; pair < n_pairs; ++pair) test_pair(pair, std::false_type());
+        // the class masks move along with the loop, two bits a pair; past slot 63 they have run empty
+        unsigned long long about_y = sv.rect_about_y, about_x = sv.rect_about_x;
+        for (uint32_t pair = 0; pair < n_pairs; ++pair, about_y >>= 2, about_x >>= 2)
+            test_pair(pair, (uint32_t)about_y, (uint32_t)about_x, std::false_type());
     }
     st.mark(ST_RECTS);
     Closest c;
