@@ -326,12 +326,13 @@ hipError_t launch_variant(const rt_context* ctx, const Launch& L, size_t lds_byt
 }
 
 // Every instantiation of the render kernel: (intersect mode, stream layout, primitive kinds, stage).  WIDE8,
-// the throughput mode, has a variant per primitive mix (rectangles only / spheres only / at most 64 spheres
-// only / both); SCALAR runs the general one.  Stages 1 and 2 exist for the per-pixel stream layout only.
+// the throughput mode, has a variant per primitive mix (rectangles only, with or without rectangles turned about
+// one axis / spheres only / at most 64 spheres only / both); SCALAR runs the general one.  Stages 1 and 2 exist for the per-pixel stream layout only.
 #define RT_FOR_EACH_STAGE(X, IM, PR)                                                             \
     X(IM, RT_RNG_ROW_SERIAL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 0) X(IM, RT_RNG_PIXEL, PR, 1) X(IM, RT_RNG_PIXEL, PR, 2)
 #define RT_FOR_EACH_KERNEL(X)                                                                    \
-    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_RECTS) RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_SPHERES) \
+    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_RECTS) RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_CLASSED_RECTS) \
+    RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_SPHERES)                                  \
     RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_FEW_SPHERES)                              \
     RT_FOR_EACH_STAGE(X, RT_INTERSECT_WIDE8, rt::PRIMS_BOTH) RT_FOR_EACH_STAGE(X, RT_INTERSECT_SCALAR, rt::PRIMS_BOTH)
 
@@ -356,7 +357,8 @@ hipError_t launch(const rt_context* ctx, const Launch& L, int stage, uint32_t* d
     // RT_INTERSECT_WIDE4 is the wide routine on an image whose primitives are dealt to four lanes: same kernels.
     const int kernel_imode = L.imode == RT_INTERSECT_WIDE4 ? RT_INTERSECT_WIDE8 : L.imode;
     const int prims = kernel_imode != RT_INTERSECT_WIDE8 ? rt::PRIMS_BOTH : ctx->mixed ? rt::PRIMS_BOTH
-                      : !ctx->sphere_count ? rt::PRIMS_RECTS : ctx->sphere_count <= 64u ? rt::PRIMS_FEW_SPHERES : rt::PRIMS_SPHERES;
+                      : !ctx->sphere_count ? ((L.kp.rect_about_y | L.kp.rect_about_x) ? rt::PRIMS_CLASSED_RECTS : rt::PRIMS_RECTS)
+                      : ctx->sphere_count <= 64u ? rt::PRIMS_FEW_SPHERES : rt::PRIMS_SPHERES;
 #define RT_DISPATCH(IM, RM, PR, ST)                                                  \
     if (kernel_imode == IM && L.rmode == RM && prims == PR && stage == ST)           \
         return launch_variant<IM, RM, PR, ST>(ctx, L, lds, image, d_pixels, d_radiance, d_rays, ws, stream, plan_only);
@@ -791,11 +793,14 @@ static rt_status upload_world_impl(rt_context* ctx, const rt_world* w) {
     // Size stage 2 for this world's kernel variants now (an occupancy query each), so that no later launch -
     // a captured one, or the entry point that must not allocate - is the first to ask.  Best effort: the world
     // is in place, and a failed query only means the default of 16 waves per CU (stage2_waves_per_cu).
-    for (int imode : {RT_INTERSECT_WIDE8, RT_INTERSECT_SCALAR}) {
-        Launch L;
-        L.imode = imode; L.rmode = RT_RNG_PIXEL; L.blocks = 1; L.block_threads = workgroup_threads(ctx);
-        (void)launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true);
-    }
+    for (int imode : {RT_INTERSECT_WIDE8, RT_INTERSECT_SCALAR, RT_INTERSECT_WIDE4})
+        for (int classed = 0; classed < 2; ++classed) {   // with the class masks, and as RT_FLAG_DENSE_TRANSFORMS renders
+            Launch L{};
+            L.imode = imode; L.rmode = RT_RNG_PIXEL; L.blocks = 1; L.block_threads = workgroup_threads(ctx);
+            L.kp.rect_about_y = classed ? ctx->rect_about_y[imode] : 0ull;
+            L.kp.rect_about_x = classed ? ctx->rect_about_x[imode] : 0ull;
+            (void)launch(ctx, L, 2, nullptr, nullptr, nullptr, ctx->ws, nullptr, /*plan_only=*/true);
+        }
     return RT_OK;
 }
 

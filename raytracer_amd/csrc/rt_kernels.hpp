@@ -116,7 +116,10 @@ struct Stamps {
 // PRIMS_FEW_SPHERES: spheres only, at most 64 of them - all records fit the wave's LDS slice, which is then
 // filled once per wave instead of once per ray, and hits read centre and tag from it instead of from global
 // memory; no register set is spent on reading ahead, so more waves fit a SIMD.
-enum : int { PRIMS_RECTS = 1, PRIMS_SPHERES = 2, PRIMS_BOTH = 3, PRIMS_FEW = 4, PRIMS_FEW_SPHERES = PRIMS_SPHERES | PRIMS_FEW };
+// PRIMS_CLASSED_RECTS: rectangles only, some of them turned about one axis (rt_layout.hpp, rect_sparsity_class):
+// the rectangle loop dispatches on the class of every rectangle; the plain variants run the full transforms.
+enum : int { PRIMS_RECTS = 1, PRIMS_SPHERES = 2, PRIMS_BOTH = 3, PRIMS_FEW = 4, PRIMS_FEW_SPHERES = PRIMS_SPHERES | PRIMS_FEW,
+             PRIMS_CLASSED = 8, PRIMS_CLASSED_RECTS = PRIMS_RECTS | PRIMS_CLASSED };
 
 struct V3 { float x, y, z; };
 
@@ -586,51 +589,31 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
     st.mark(ST_SPHERE_TERMS);
     // Rectangles (main.cpp:96-129 / 212-239): ray into the rectangle's frame, hit the
     // z = 0 plane, test against the unit square.  The scene image stores them in pairs (rows 0 and 1 of A, of B,
-    // then the two row-2 vectors), and a step of the loop tests the two rectangles of a pair, each by the copy of
-    // the test that matches the exact zeros of its matrix (rect_sparsity_class; a scalar branch on the host's
-    // masks): a rectangle turned about one axis costs 10 multiply-adds for the transforms instead of 18.
+    // then the two row-2 vectors) and a step of the loop tests the two rectangles of a pair.
+    //   Plain variants: both full transforms side by side, which gives the scheduler twelve independent
+    //   multiply-add chains and two divisions to interleave.
+    //   PRIMS_CLASSED (worlds in which some rectangle is turned about one axis, rect_sparsity_class): each
+    //   rectangle's transforms by the copy of the arithmetic that matches the exact zeros of its matrix, chosen by
+    //   a scalar branch on the host's class masks - 10 multiply-adds instead of 18 for a classed rectangle; the
+    //   division, the hit point and the closest-hit update follow once, after the copies have joined.
+    constexpr bool CLASSED = (PRIMS & PRIMS_CLASSED) != 0;
     const uint32_t rect_base = 1 + sv.n_planes + sv.n_spheres;
     const uint32_t n_pairs = (PRIMS & PRIMS_RECTS) && active ? sv.n_rects / 2 : 0u;
     // One pair.  CAMERA is a compile-time copy of camera_origin: the loop exists twice, so that neither copy
-    // branches on it.
-    // about_y / about_x: sparsity classes of the pair's two slots in bits 0 (A) and 1 (B); higher bits are ignored.
+    // branches on it.  about_y / about_x (CLASSED): sparsity classes of the pair's two slots in bits 0 (A) and
+    // 1 (B); higher bits are ignored.
     auto test_pair = [&](uint32_t pair, uint32_t about_y, uint32_t about_x, auto camera_tag) {
         constexpr bool CAMERA = decltype(camera_tag)::value;
         const float4* rec = reinterpret_cast<const float4*>(sv.f + sv.off_rects + RECT_PAIR_WORDS * pair);
-        // Row 2 of both rectangles (and the camera rows) are read once per pair.  Reading them per rectangle would
-        // free four registers and a wave per SIMD more would fit (61 instead of 65), but the two extra LDS reads per
-        // pair cost more than the eighth wave brings (16.55 against 16.29 ms on the Cornell bench).
+        // Row 2 of both rectangles (and the camera rows) are read once per pair.  (CLASSED: reading them per
+        // rectangle would free four registers, but the two extra LDS reads per pair cost more than that brings:
+        // 16.55 against 16.29 ms on the Cornell bench.)
         const float4 z01 = rec[4], z23 = rec[5];
         float4 c01 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c2 = c01;
         if (CAMERA) { c01 = rec[8]; c2 = rec[9]; }
-        auto one = [&](auto which_tag) -> float {
-            constexpr int which = decltype(which_tag)::value;
-            const float4 r01 = rec[2 * which], r23 = rec[2 * which + 1];   // (m00 m10 m01 m11) (m02 m12 m03 m13)
-            const float m20 = which ? z01.y : z01.x, m21 = which ? z01.w : z01.z, m22 = which ? z23.y : z23.x, m23 = which ? z23.w : z23.z;
-            // t and the hit point in the rectangle's frame, by the copy of the arithmetic for the matrix's class; the
-            // closest-hit update follows once, after the copies have joined.
-            float t, hx, hy;
-            auto body = [&](auto sparsity_tag) {
-                constexpr int S = decltype(sparsity_tag)::value;
-                constexpr bool Z01 = S != 0, Z10 = S != 0, Z12 = S == 1, Z21 = S == 1, Z02 = S == 2, Z20 = S == 2;
-                float lo_x, lo_y, lo_z;     // the origin in the rectangle's frame
-                if (CAMERA) {
-                    lo_x = which ? c01.z : c01.x; lo_y = which ? c01.w : c01.y; lo_z = which ? c2.y : c2.x;
-                } else {
-                    lo_x = affine_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, r23.z, o);
-                    lo_y = affine_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, r23.w, o);
-                    lo_z = affine_row<IMODE, Z20, Z21, false>(m20, m21, m22, m23, o);
-                }
-                const float ld_x = linear_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, d);
-                const float ld_y = linear_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, d);
-                const float ld_z = linear_row<IMODE, Z20, Z21, false>(m20, m21, m22, d);
-                t = div1(-lo_z, ld_z);   // t = (-origin'.z) / direction'.z
-                hx = lo_x + ld_x * t;
-                hy = lo_y + ld_y * t;
-            };
-            if ((about_y >> which) & 1u) body(std::integral_constant<int, 1>());
-            else if ((about_x >> which) & 1u) body(std::integral_constant<int, 2>());
-            else body(std::integral_constant<int, 0>());
+        float t_a, t_b;
+        // if (min_hit < t < best_t inside the unit square) the rectangle becomes the closest hit
+        auto update = [&](int which, float hx, float hy, float t) {
 #ifdef RT_STAMPS
             // rectangles that no lane's t passes min_hit < t < closest so far
             st.count(CT_RECTS_OUT_OF_RANGE, ballot(t > min_hit && t < best_t) == 0ull ? 1 : 0);
@@ -649,10 +632,71 @@ __device__ __forceinline__ Closest intersect_world(const SceneView& sv, V3 o, V3
                     best_lane = 0;
                 }
             }
-            return t;
         };
-        const float t_a = one(std::integral_constant<int, 0>());
-        const float t_b = one(std::integral_constant<int, 1>());
+        if (!CLASSED) {
+            const float4 a01 = rec[0], a23 = rec[1], b01 = rec[2], b23 = rec[3];
+            const F2 ox2 = splat(o.x), oy2 = splat(o.y), oz2 = splat(o.z), dx2 = splat(d.x), dy2 = splat(d.y), dz2 = splat(d.z);
+            F2 a_lo, a_ld, b_lo, b_ld, z_lo, z_ld;   // (row0, row1) of A, of B; (A.row2, B.row2)
+            if (CAMERA) {
+                a_lo = f2(c01.x, c01.y); b_lo = f2(c01.z, c01.w); z_lo = f2(c2.x, c2.y);
+            } else if (IMODE == RT_INTERSECT_WIDE8) {
+                // DotProduct(LaneVector4): fma(x,x', fma(y,y', fma(z,z', w*w'))) with w' = 1 for the
+                // origin (w*1 is exact).
+                a_lo = fma2(f2(a01.x, a01.y), ox2, fma2(f2(a01.z, a01.w), oy2, fma2(f2(a23.x, a23.y), oz2, f2(a23.z, a23.w))));
+                b_lo = fma2(f2(b01.x, b01.y), ox2, fma2(f2(b01.z, b01.w), oy2, fma2(f2(b23.x, b23.y), oz2, f2(b23.z, b23.w))));
+                z_lo = fma2(f2(z01.x, z01.y), ox2, fma2(f2(z01.z, z01.w), oy2, fma2(f2(z23.x, z23.y), oz2, f2(z23.z, z23.w))));
+            } else {
+                // DotProduct(Vector4): x*x' + y*y' + z*z' + w*w', left to right (math_vector.h:341-343).
+                a_lo = f2(a01.x, a01.y) * ox2 + f2(a01.z, a01.w) * oy2 + f2(a23.x, a23.y) * oz2 + f2(a23.z, a23.w);
+                b_lo = f2(b01.x, b01.y) * ox2 + f2(b01.z, b01.w) * oy2 + f2(b23.x, b23.y) * oz2 + f2(b23.z, b23.w);
+                z_lo = f2(z01.x, z01.y) * ox2 + f2(z01.z, z01.w) * oy2 + f2(z23.x, z23.y) * oz2 + f2(z23.z, z23.w);
+            }
+            if (IMODE == RT_INTERSECT_WIDE8) {
+                // w' = 0 for the direction (adds a zero: only the sign of an exact zero could differ,
+                // which no comparison below can see).
+                a_ld = fma2(f2(a01.x, a01.y), dx2, fma2(f2(a01.z, a01.w), dy2, f2(a23.x, a23.y) * dz2));
+                b_ld = fma2(f2(b01.x, b01.y), dx2, fma2(f2(b01.z, b01.w), dy2, f2(b23.x, b23.y) * dz2));
+                z_ld = fma2(f2(z01.x, z01.y), dx2, fma2(f2(z01.z, z01.w), dy2, f2(z23.x, z23.y) * dz2));
+            } else {
+                a_ld = f2(a01.x, a01.y) * dx2 + f2(a01.z, a01.w) * dy2 + f2(a23.x, a23.y) * dz2;
+                b_ld = f2(b01.x, b01.y) * dx2 + f2(b01.z, b01.w) * dy2 + f2(b23.x, b23.y) * dz2;
+                z_ld = f2(z01.x, z01.y) * dx2 + f2(z01.z, z01.w) * dy2 + f2(z23.x, z23.y) * dz2;
+            }
+            const F2 t2 = div2(-z_lo, z_ld);   // t = (-origin'.z) / direction'.z for A and B
+            t_a = t2.x; t_b = t2.y;
+            const F2 ha = a_lo + a_ld * splat(t_a), hb = b_lo + b_ld * splat(t_b);
+            update(0, ha.x, ha.y, t_a);
+            update(1, hb.x, hb.y, t_b);
+        } else {
+            auto one = [&](auto which_tag) -> float {
+                constexpr int which = decltype(which_tag)::value;
+                const float4 r01 = rec[2 * which], r23 = rec[2 * which + 1];   // (m00 m10 m01 m11) (m02 m12 m03 m13)
+                const float m20 = which ? z01.y : z01.x, m21 = which ? z01.w : z01.z, m22 = which ? z23.y : z23.x, m23 = which ? z23.w : z23.z;
+                float lo_x, lo_y, lo_z, ld_x, ld_y, ld_z;   // origin and direction in the rectangle's frame
+                auto transforms = [&](auto sparsity_tag) {
+                    constexpr int S = decltype(sparsity_tag)::value;
+                    constexpr bool Z01 = S != 0, Z10 = S != 0, Z12 = S == 1, Z21 = S == 1, Z02 = S == 2, Z20 = S == 2;
+                    if (CAMERA) {
+                        lo_x = which ? c01.z : c01.x; lo_y = which ? c01.w : c01.y; lo_z = which ? c2.y : c2.x;
+                    } else {
+                        lo_x = affine_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, r23.z, o);
+                        lo_y = affine_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, r23.w, o);
+                        lo_z = affine_row<IMODE, Z20, Z21, false>(m20, m21, m22, m23, o);
+                    }
+                    ld_x = linear_row<IMODE, false, Z01, Z02>(r01.x, r01.z, r23.x, d);
+                    ld_y = linear_row<IMODE, Z10, false, Z12>(r01.y, r01.w, r23.y, d);
+                    ld_z = linear_row<IMODE, Z20, Z21, false>(m20, m21, m22, d);
+                };
+                if ((about_y >> which) & 1u) transforms(std::integral_constant<int, 1>());
+                else if ((about_x >> which) & 1u) transforms(std::integral_constant<int, 2>());
+                else transforms(std::integral_constant<int, 0>());
+                const float t = div1(-lo_z, ld_z);   // t = (-origin'.z) / direction'.z
+                update(which, lo_x + ld_x * t, lo_y + ld_y * t, t);
+                return t;
+            };
+            t_a = one(std::integral_constant<int, 0>());
+            t_b = one(std::integral_constant<int, 1>());
+        }
 #ifdef RT_STAMPS
         // pairs whose two planes lie behind every ray of the wave (t <= 0 on all lanes)
         st.count(CT_RECT_PAIRS, 1);
@@ -873,7 +917,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
     // per-lane loop in vector registers.
     primary_pairs = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(primary_pairs >> 32)) << 32) |
                     __builtin_amdgcn_readfirstlane((uint32_t)primary_pairs);
-    const bool nothing_for_primary_rays = PRIMS == PRIMS_RECTS && sv.n_planes == 0 && sv.n_rects <= 128u &&
+    const bool nothing_for_primary_rays = (PRIMS & ~PRIMS_CLASSED) == PRIMS_RECTS && sv.n_planes == 0 && sv.n_rects <= 128u &&
                                           (primary_pairs & (sv.n_rects >= 128u ? ~0ull : (1ull << (sv.n_rects / 2u)) - 1ull)) == 0ull;
     // STAGE 2: persistent waves; every lane fetches deposited streams from the pool until it is empty.
     const uint32_t pool_count = STAGE == 2 ? min(ws.pool_count[0], p.pool_capacity) : 0u;
@@ -992,7 +1036,7 @@ __global__ __launch_bounds__(MAX_BLOCK_THREADS) void render_kernel(KernelParams 
         }
         if (in_path) {
             if (!(PRIMS & PRIMS_SPHERES)) {
-                if (PRIMS == PRIMS_RECTS && camera_origin && nothing_for_primary_rays) {
+                if ((PRIMS & ~PRIMS_CLASSED) == PRIMS_RECTS && camera_origin && nothing_for_primary_rays) {
                     // Primary rays of a tile from which no rectangle can be reached (and a world without planes): a
                     // miss, whatever the direction; the miss branch below does not read it, so it is not normalised.
                     c.t = 3.402823466e+38f;
