@@ -25,6 +25,8 @@
 // name as an address: rt_create asks the runtime for this device's copy (hipGetSymbolAddress) and the
 // context keeps that pointer.
 constexpr size_t STATIC_SCRATCH_BYTES = 32u << 20;
+// head of a compaction workspace: the pool's fill count, then (256 bytes on) the partial ray counters
+constexpr size_t COUNTER_BLOCK_BYTES = 256 + rt::RAY_SLOTS * rt::RAY_SLOT_STRIDE * sizeof(unsigned long long);
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 struct rt_context {
@@ -57,7 +59,7 @@ struct rt_context {
     uint32_t accumulator_key[6] = {0, 0, 0, 0, 0, 0};
     void* h_staging = nullptr;       // pinned host buffer the results are copied through
     // workspace of RT_FLAG_COMPACT_TAILS renders; grow-only
-    rt::Workspace ws{nullptr, nullptr, nullptr, nullptr};
+    rt::Workspace ws{nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t lane_sum_capacity = 0, pool_entry_capacity = 0, pending_capacity = 0;
     size_t staging_bytes = 0;
     unsigned long long* d_rays = nullptr;
@@ -392,7 +394,10 @@ rt_status ensure_output_capacity(rt_context* ctx, size_t count, bool want_pixels
 
 rt_status ensure_workspace(rt_context* ctx, const Launch& L) {
     const size_t streams = (size_t)L.kp.local_rows * L.kp.width * L.kp.lanes_per_pixel;
-    if (!ctx->ws.pool_count) RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.pool_count, sizeof(uint32_t)));
+    if (!ctx->ws.pool_count) {   // the pool's fill count and, 256 bytes on, the partial ray counters
+        RT_HIP_CHECK(ctx, hipMalloc(&ctx->ws.pool_count, COUNTER_BLOCK_BYTES));
+        ctx->ws.ray_slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(ctx->ws.pool_count) + 256);
+    }
     if (streams > ctx->lane_sum_capacity) {
         if (ctx->ws.lane_sums) { RT_HIP_CHECK(ctx, hipFree(ctx->ws.lane_sums)); ctx->ws.lane_sums = nullptr; }
         ctx->lane_sum_capacity = 0;
@@ -495,11 +500,12 @@ rt_status guarded(Body&& body) noexcept {
 
 // Layout of the fixed per-GPU workspace behind rt_render_device_noalloc (STATIC_SCRATCH_BYTES in all):
 //   [0, 256)                     fill count of the pool
-//   [256, 256 + 1 MiB)           one pending flag per pixel          -> at most 2^20 pixels
+//   [256, 4352)                  partial ray counters (rt::RAY_SLOTS x 64 bytes)
+//   [4352, 4352 + 1 MiB)         one pending flag per pixel          -> at most 2^20 pixels
 //   [.., + 16 MiB)               one float4 sum per stream            -> at most 2^20 streams (pixels x lanes_per_pixel)
 //   rest (about 15 MiB)          pool of handed-over streams, 80 bytes each
 constexpr uint64_t STATIC_MAX_PIXELS = 1u << 20, STATIC_MAX_STREAMS = 1u << 20;
-constexpr size_t STATIC_PENDING_OFFSET = 256;
+constexpr size_t STATIC_PENDING_OFFSET = COUNTER_BLOCK_BYTES;
 constexpr size_t STATIC_LANE_SUMS_OFFSET = STATIC_PENDING_OFFSET + STATIC_MAX_PIXELS;
 constexpr size_t STATIC_POOL_OFFSET = STATIC_LANE_SUMS_OFFSET + STATIC_MAX_STREAMS * sizeof(float4);
 constexpr uint64_t STATIC_POOL_ENTRIES = (STATIC_SCRATCH_BYTES - STATIC_POOL_OFFSET) / (rt::POOL_VEC4 * sizeof(uint4));
@@ -531,6 +537,7 @@ rt_status render_device(rt_context* ctx, const rt_render_params* params, uint32_
                         (unsigned long long)STATIC_MAX_STREAMS);
         unsigned char* base = ctx->static_scratch;   // this device's copy of the array, from hipGetSymbolAddress
         ws.pool_count = reinterpret_cast<uint32_t*>(base);
+        ws.ray_slots = reinterpret_cast<unsigned long long*>(base + 256);
         ws.pending = base + STATIC_PENDING_OFFSET;
         ws.lane_sums = reinterpret_cast<float4*>(base + STATIC_LANE_SUMS_OFFSET);
         ws.pool = reinterpret_cast<uint4*>(base + STATIC_POOL_OFFSET);
@@ -541,7 +548,8 @@ rt_status render_device(rt_context* ctx, const rt_render_params* params, uint32_
     }
     if (rays || L.compact) {
         // the fill count of the pool must start at zero; everything else in the workspace is written before it is read
-        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(1), 0, stream, rays, L.compact ? ws.pool_count : nullptr);
+        hipLaunchKernelGGL(rt::clear_counter_kernel, dim3(1), dim3(rt::RAY_SLOTS), 0, stream, rays, L.compact ? ws.pool_count : nullptr,
+                           L.compact ? ws.ray_slots : nullptr);
         RT_HIP_CHECK(ctx, hipGetLastError());
     }
     const bool timed = params->flags & RT_FLAG_TIME_KERNEL;
@@ -553,7 +561,8 @@ rt_status render_device(rt_context* ctx, const rt_render_params* params, uint32_
         RT_HIP_CHECK(ctx, launch(ctx, L, 2, d_pixels, d_radiance, rays, ws, stream));
         const size_t pixel_count = (size_t)L.kp.local_rows * L.kp.width;
         hipLaunchKernelGGL(rt::pixel_combine_kernel, dim3((uint32_t)((pixel_count + rt::BLOCK_THREADS - 1) / rt::BLOCK_THREADS)),
-                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ws.lane_sums, ws.pending, d_pixels, d_radiance);
+                           dim3(rt::BLOCK_THREADS), 0, stream, L.kp, ws.lane_sums, ws.pending, d_pixels, d_radiance,
+                           ws.ray_slots, rays);
         RT_HIP_CHECK(ctx, hipGetLastError());
     }
     if (timed) RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, stream));

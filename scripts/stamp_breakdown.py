@@ -3,7 +3,7 @@
 of the library (build/librt_hip_stamps.so, compiled with -DRT_STAMPS) and prints the share of wave cycles
 per region of the loop and the lane counts of the divergent blocks.
 
-    RT_HIP_LIBRARY=$PWD/build/librt_hip_stamps.so python scripts/stamp_breakdown.py cornell glass ...
+    RT_HIP_LIBRARY=$PWD/build/librt_hip_stamps.so python scripts/stamp_breakdown.py [--no-cull] [--spp=N] cornell glass ...
 """
 import ctypes as C
 import pathlib
@@ -33,6 +33,9 @@ def main():
     for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["cornell"]:
         cfg = bench.CONFIGS[name]
         spp = max(cfg["lanes"] * 64, cfg["spp"] // 4)
+        for a in sys.argv[1:]:
+            if a.startswith("--spp="):
+                spp = int(a[6:])
         with B.Context(0) as ctx:
             ctx.upload_world(build_scene(*cfg["scene"]))
             p = B.default_params(cfg["width"], cfg["height"], spp, lanes_per_pixel=cfg["lanes"], max_bounces=cfg["bounces"],
