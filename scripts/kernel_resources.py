@@ -6,7 +6,7 @@ import sys
 
 text = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/rt_api.resource.txt").read()
 for block in re.split(r"Function Name: ", text)[1:]:
-    m = re.match(r"_ZN2rt13render_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)", block.split()[0])
+    m = re.match(r"_ZN2rt13render_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", block.split()[0])
     if not m:
         continue
     get = lambda key: re.search(key + r": (\d+)", block).group(1)
